@@ -1,0 +1,102 @@
+"""Synthetic benchmark table of SURVEY.md section 8c(ii) / 8d (numpy, host side).
+
+  x_0 = seed; per row: x ^= x << 13; x ^= x >> 7; x ^= x << 17  (xorshift64)
+  k = x % 1000, a = (x >> 8) & 0xffff, b = (x >> 24) & 0xffff,
+  v = (x >> 40) / 1024.0, n = i (NULL when i % 3 == 0), s = "g" + str(k)
+
+The device generator (evql_table_generate) produces the same sequence with a
+GF(2) jump-ahead; this module is the host twin used to build small tables and
+to check the device generator.
+"""
+import numpy as np
+
+SEED = 88172645463325252
+MASK = (1 << 64) - 1
+
+
+def xorshift64_sequence(n, seed=SEED):
+    """x_1 .. x_n (state after each step)"""
+    out = np.empty(n, dtype=np.uint64)
+    x = seed
+    for i in range(n):
+        x ^= (x << 13) & MASK
+        x ^= x >> 7
+        x ^= (x << 17) & MASK
+        out[i] = x
+    return out
+
+
+def _step_matrix():
+    """64x64 GF(2) matrix of one xorshift step as 64 column images"""
+    cols = []
+    for bit in range(64):
+        x = 1 << bit
+        x ^= (x << 13) & MASK
+        x ^= x >> 7
+        x ^= (x << 17) & MASK
+        cols.append(x)
+    return cols
+
+
+def _mat_apply(cols, x):
+    r = 0
+    b = 0
+    while x:
+        if x & 1:
+            r ^= cols[b]
+        x >>= 1
+        b += 1
+    return r
+
+
+def _mat_mul(a, b):
+    """(a o b): apply b first, then a"""
+    return [_mat_apply(a, c) for c in b]
+
+
+def jump_matrices(nbits=40):
+    """M^(2^j) for j < nbits, each as 64 column images (python ints)"""
+    m = _step_matrix()
+    out = [m]
+    for _ in range(1, nbits):
+        m = _mat_mul(m, m)
+        out.append(m)
+    return out
+
+
+def xorshift64_sequence_fast(n, seed=SEED, chunk=4096):
+    """vectorised: jump to the start of every chunk, then step all chunks in
+    lock-step with numpy"""
+    nchunks = (n + chunk - 1) // chunk
+    # state at the start of chunk c = M^(c*chunk) seed
+    mats = jump_matrices(48)
+    starts = np.empty(nchunks, dtype=np.uint64)
+    # incremental: M^chunk applied repeatedly
+    mc = None
+    e, j = chunk, 0
+    while e:
+        if e & 1:
+            mc = mats[j] if mc is None else _mat_mul(mats[j], mc)
+        e >>= 1
+        j += 1
+    x = seed
+    for c in range(nchunks):
+        starts[c] = x
+        x = _mat_apply(mc, x)
+    out = np.empty((nchunks, chunk), dtype=np.uint64)
+    s = starts.copy()
+    for i in range(chunk):
+        s ^= s << np.uint64(13)
+        s ^= s >> np.uint64(7)
+        s ^= s << np.uint64(17)
+        out[:, i] = s
+    return out.reshape(-1)[:n]
+
+
+def table_columns(n, seed=SEED, k_mod=1000):
+    x = xorshift64_sequence_fast(n, seed)
+    k = x % np.uint64(k_mod)
+    a = (x >> np.uint64(8)) & np.uint64(0xFFFF)
+    b = (x >> np.uint64(24)) & np.uint64(0xFFFF)
+    v = (x >> np.uint64(40)).astype(np.float64) / 1024.0
+    return dict(x=x, k=k, a=a, b=b, v=v)

@@ -1,0 +1,438 @@
+/*
+ * evql_gpu.h -- C ABI of the MI355X scan -> filter -> GROUP BY executor.
+ *
+ * This is the drop-in boundary: plain pointers and
+ * sizes, no C++/torch types, never throws.  Each entry point names the
+ * reference interface (file:line under 17ai/eventql) it stands in for; the
+ * reference-side adapter (a csql::TableExpression subclass and a
+ * csql::DefaultScheduler override) that binds these is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns EVQL_OK (0) or a negative evql_status; the message
+ *     of the last failure on the calling thread is evql_last_error()
+ *     (reference: ReturnCode::error(code,msg), util/return_code.h:32-80)
+ *   - one thread drives one query object (reference threading model: pull
+ *     operators are never called concurrently, SURVEY 8b "Threading")
+ *   - there is NO CPU fallback behind this ABI: if the HIP device or the kernel
+ *     compiler is unavailable every compute entry point fails with
+ *     EVQL_EDEVICE.
+ */
+#ifndef EVQL_GPU_H
+#define EVQL_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* status codes (string codes of util/return_code.h mapped to integers)      */
+/* ------------------------------------------------------------------------ */
+typedef enum {
+  EVQL_OK = 0,
+  EVQL_EIO = -1,      /* "EIO"      */
+  EVQL_EARG = -2,     /* "EARG"     */
+  EVQL_ERUNTIME = -3, /* "ERUNTIME" (incl. "division by zero") */
+  EVQL_ENOTSUP = -4,  /* plan not lowerable: caller falls back to CPU operators */
+  EVQL_EDEVICE = -5,  /* HIP device / hiprtc unavailable or failed */
+  EVQL_ENOMEM = -6
+} evql_status;
+
+const char* evql_last_error(void);
+const char* evql_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* value model: mirrors csql::SType / STag (sql/svalue.h:41-56)               */
+/* ------------------------------------------------------------------------ */
+typedef enum {
+  EVQL_T_NIL = 0,
+  EVQL_T_UINT64 = 1,
+  EVQL_T_INT64 = 2,
+  EVQL_T_FLOAT64 = 3,
+  EVQL_T_BOOL = 4,
+  EVQL_T_STRING = 5,
+  EVQL_T_TIMESTAMP64 = 6
+} evql_stype;
+
+#define EVQL_STAG_NULL 1
+
+/* cstable column model (io/cstable/cstable.h:113-131) */
+typedef enum {
+  EVQL_COL_SUBRECORD = 0,
+  EVQL_COL_BOOLEAN = 1,
+  EVQL_COL_UNSIGNED_INT = 2,
+  EVQL_COL_SIGNED_INT = 3,
+  EVQL_COL_STRING = 4,
+  EVQL_COL_FLOAT = 5,
+  EVQL_COL_DATETIME = 6
+} evql_column_type;
+
+typedef enum {
+  EVQL_ENC_BOOLEAN_BITPACKED = 1,
+  EVQL_ENC_UINT32_BITPACKED = 10,
+  EVQL_ENC_UINT32_PLAIN = 11,
+  EVQL_ENC_UINT64_PLAIN = 12,
+  EVQL_ENC_UINT64_LEB128 = 13,
+  EVQL_ENC_FLOAT_IEEE754 = 14,
+  EVQL_ENC_STRING_PLAIN = 100
+} evql_column_encoding;
+
+/* ------------------------------------------------------------------------ */
+/* bytecode: mirrors csql::vm::Instruction / vm::Program (runtime/vm.h:44-82) */
+/* ------------------------------------------------------------------------ */
+typedef enum {
+  EVQL_X_CALL_PURE = 1,
+  EVQL_X_CALL_INSTANCE = 2,
+  EVQL_X_LITERAL = 3,
+  EVQL_X_INPUT = 4,
+  EVQL_X_JUMP = 5,
+  EVQL_X_CJUMP = 6,
+  EVQL_X_RETURN = 7
+} evql_opcode;
+
+/*
+ * Pure functions: the reference stores a C function pointer in
+ * Instruction::arg0; across the ABI it becomes one of these ids.  The adapter
+ * maps by symbol string "name#ret/arg;arg;" (runtime/symboltable.cc:33-41).
+ * Numbering: family * 16 + type-slot.
+ */
+typedef enum {
+  EVQL_TS_UINT64 = 0,
+  EVQL_TS_INT64 = 1,
+  EVQL_TS_FLOAT64 = 2,
+  EVQL_TS_BOOL = 3,
+  EVQL_TS_STRING = 4,
+  EVQL_TS_TIMESTAMP64 = 5,
+  EVQL_TS_NIL = 6
+} evql_type_slot;
+
+typedef enum {
+  EVQL_FAM_LOGICAL_AND = 1, /* boolean.cc:38  */
+  EVQL_FAM_LOGICAL_OR = 2,  /* boolean.cc:52  */
+  EVQL_FAM_NEG = 3,         /* boolean.cc:66  */
+  EVQL_FAM_CMP = 4,         /* boolean.cc:81-180  -> int64 -1/0/1 */
+  EVQL_FAM_EQ = 5,
+  EVQL_FAM_NEQ = 6,
+  EVQL_FAM_LT = 7,
+  EVQL_FAM_LTE = 8,
+  EVQL_FAM_GT = 9,
+  EVQL_FAM_GTE = 10,
+  EVQL_FAM_ADD = 11, /* math.cc:34-  */
+  EVQL_FAM_SUB = 12,
+  EVQL_FAM_MUL = 13,
+  EVQL_FAM_DIV = 14, /* int/uint division by zero => ERUNTIME */
+  EVQL_FAM_MOD = 15,
+  EVQL_FAM_POW = 16,
+  EVQL_FAM_TO_NIL = 17,   /* conversion.cc:34-93   */
+  EVQL_FAM_TO_INT64 = 18, /* conversion.cc:96-137  */
+  EVQL_FAM_TO_TIMESTAMP64 = 19
+} evql_fn_family;
+
+#define EVQL_FN(family, type_slot) ((int64_t)(family) * 16 + (int64_t)(type_slot))
+
+/*
+ * Aggregate functions (X_CALL_INSTANCE).  count / sum_uint64 / sum_int64 are
+ * the reference's live aggregates (expressions/aggregate.cc:35-219); the rest
+ * are supplied by this build under the same SFunction vtable contract
+ * (SFunction.h:41-86) because BASELINE.json's north_star asks for them
+ * (SURVEY.md header, 8a a15).
+ */
+typedef enum {
+  EVQL_AGG_NONE = 0,
+  EVQL_AGG_COUNT = 1,       /* count#uint64/nil;      counts NULLs too      */
+  EVQL_AGG_SUM_UINT64 = 2,  /* sum#uint64/uint64;     wraps mod 2^64        */
+  EVQL_AGG_SUM_INT64 = 3,   /* sum#int64/int64;                             */
+  EVQL_AGG_SUM_FLOAT64 = 4, /* sum#float64/float64;   build-supplied        */
+  EVQL_AGG_MIN_UINT64 = 5,  /* min/max/mean skip STAG_NULL inputs; empty => NULL */
+  EVQL_AGG_MAX_UINT64 = 6,
+  EVQL_AGG_MIN_INT64 = 7,
+  EVQL_AGG_MAX_INT64 = 8,
+  EVQL_AGG_MIN_FLOAT64 = 9,
+  EVQL_AGG_MAX_FLOAT64 = 10,
+  EVQL_AGG_MEAN_UINT64 = 11, /* -> float64 */
+  EVQL_AGG_MEAN_INT64 = 12,
+  EVQL_AGG_MEAN_FLOAT64 = 13,
+  EVQL_AGG_COUNT_DISTINCT_UINT64 = 14 /* not lowerable: EVQL_ENOTSUP */
+} evql_aggregate_fn;
+
+/* X_CALL_INSTANCE arg0 */
+#define EVQL_INSTANCE_ACCUMULATE 1
+#define EVQL_INSTANCE_GET 2
+
+typedef struct {
+  uint32_t op;   /* evql_opcode */
+  uint32_t argt; /* evql_stype of a literal / input */
+  int64_t arg0;  /* CALL_PURE: EVQL_FN(..); CALL_INSTANCE: ACCUMULATE|GET;
+                    LITERAL: byte offset into static_storage; INPUT: column
+                    index; JUMP/CJUMP: target pc */
+} evql_instr_t;
+
+typedef struct {
+  const evql_instr_t* code;
+  uint32_t code_len;
+  uint32_t method_call;       /* entry pc (vm::Program::method_call.offset) */
+  uint32_t method_accumulate; /* entry pc; > 0 <=> aggregate program        */
+  uint32_t return_type;       /* evql_stype */
+  uint32_t aggregate_fn;      /* evql_aggregate_fn when method_accumulate > 0 */
+  /* literal pool: each literal is its value bytes followed by one tag byte
+   * (strings: u32 len, bytes, tag), i.e. the VM stack element layout */
+  const uint8_t* static_storage;
+  size_t static_storage_len;
+} evql_program_t;
+
+/* ------------------------------------------------------------------------ */
+/* context                                                                    */
+/* ------------------------------------------------------------------------ */
+typedef struct evql_ctx evql_ctx_t;
+typedef struct evql_table evql_table_t;
+typedef struct evql_query evql_query_t;
+typedef struct evql_writer evql_writer_t;
+
+/* Binds to HIP device `device_ordinal`.  Fails with EVQL_EDEVICE when no GPU
+ * is visible. `stream` may be NULL (a private stream is created) or an existing
+ * hipStream_t (e.g. torch's current stream). */
+int evql_ctx_create(int device_ordinal, void* stream, evql_ctx_t** out);
+void evql_ctx_destroy(evql_ctx_t* ctx);
+int evql_ctx_synchronize(evql_ctx_t* ctx);
+void* evql_ctx_stream(evql_ctx_t* ctx);
+
+/* ------------------------------------------------------------------------ */
+/* tables: a cstable v0.2.0 file resident in HBM                              */
+/* ------------------------------------------------------------------------ */
+
+/* cstable::CSTableReader::openFile (io/cstable/cstable_reader.cc:133-200):
+ * parse header / metablock / index, copy the page area to HBM. */
+int evql_table_open_file(evql_ctx_t* ctx, const char* path, evql_table_t** out);
+
+/* same for an in-memory image (reference: CSTableReader::openFile(arena),
+ * cstable_reader.cc:202-230) */
+int evql_table_open_image(evql_ctx_t* ctx, const void* image, size_t len,
+                          evql_table_t** out);
+
+void evql_table_close(evql_table_t* t);
+uint64_t evql_table_num_rows(const evql_table_t* t);
+int evql_table_num_columns(const evql_table_t* t);
+
+typedef struct {
+  char name[256];
+  int32_t logical_type; /* evql_column_type */
+  int32_t storage_type; /* evql_column_encoding */
+  uint64_t column_id;
+  uint32_t rlevel_max;
+  uint32_t dlevel_max;
+  uint32_t n_data_pages;
+  uint32_t n_rlevel_pages;
+  uint32_t n_dlevel_pages;
+  uint64_t payload_bytes; /* algorithmic bytes of all streams */
+} evql_column_info_t;
+
+int evql_table_column_info(const evql_table_t* t, int idx,
+                           evql_column_info_t* out);
+/* size / copy-out of the image as it sits in HBM (tests of the generator) */
+uint64_t evql_table_image_size(const evql_table_t* t);
+int evql_table_download_image(const evql_table_t* t, void* dst, uint64_t len);
+
+/*
+ * Synthetic table generated directly into HBM in cstable v0.2.0 page layout
+ * (the same bytes TableWriter would produce), SURVEY.md 8c(ii)/8d:
+ *   x_i = xorshift64 (seed, shifts 13/7/17), stepped once per row
+ *   k = x % k_mod, a = (x>>8)&0xffff, b = (x>>24)&0xffff,
+ *   v = (x>>40)/1024.0, u = x % u_mod (0 = absent)
+ * Columns present: bit0 k, bit1 a, bit2 b, bit3 v, bit4 u.  Encodings are
+ * UINT64_PLAIN / FLOAT_IEEE754, or UINT32_BITPACKED of width k_bits for k
+ * when k_bits > 0.
+ */
+typedef struct {
+  uint64_t num_rows;
+  uint64_t seed;
+  uint64_t k_mod;
+  uint64_t u_mod;
+  uint32_t columns;
+  uint32_t k_bits;
+} evql_synth_spec_t;
+
+int evql_table_generate(evql_ctx_t* ctx, const evql_synth_spec_t* spec,
+                        evql_table_t** out);
+
+/* ------------------------------------------------------------------------ */
+/* host-side cstable writer (inputs for tests / loaders)                      */
+/*   cstable::CSTableWriter (io/cstable/cstable_writer.cc:46-310)             */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const char* name;
+  int32_t logical_type;
+  int32_t storage_type;
+  uint64_t column_id;
+  uint32_t rlevel_max;
+  uint32_t dlevel_max;
+  uint32_t bitpack_max_value; /* 0 => reference default (0xffffffff / 1) */
+} evql_column_spec_t;
+
+int evql_writer_create(const evql_column_spec_t* cols, int ncols,
+                       evql_writer_t** out);
+/* bulk appends to one column.  rlvl/dlvl may be NULL (0 / dlevel_max);
+ * present may be NULL (all present).  A slot with dlvl != dlevel_max (or
+ * present == 0) is written as a NULL (ColumnWriter::writeNull). */
+int evql_writer_put_uint(evql_writer_t* w, int col, uint64_t n,
+                         const uint64_t* rlvl, const uint64_t* dlvl,
+                         const uint8_t* present, const uint64_t* values);
+int evql_writer_put_float(evql_writer_t* w, int col, uint64_t n,
+                          const uint64_t* rlvl, const uint64_t* dlvl,
+                          const uint8_t* present, const double* values);
+int evql_writer_put_string(evql_writer_t* w, int col, uint64_t n,
+                           const uint64_t* rlvl, const uint64_t* dlvl,
+                           const uint8_t* present, const uint64_t* offsets,
+                           const char* bytes);
+int evql_writer_commit(evql_writer_t* w, uint64_t num_rows);
+const void* evql_writer_image(const evql_writer_t* w, uint64_t* len);
+int evql_writer_write_file(const evql_writer_t* w, const char* path);
+void evql_writer_destroy(evql_writer_t* w);
+
+/* ------------------------------------------------------------------------ */
+/* the operator: GroupByExpression over FastCSTableScan / CSTableScan         */
+/* ------------------------------------------------------------------------ */
+typedef enum {
+  /* GroupByExpression (groupby.cc:69-220): final values */
+  EVQL_MODE_FINAL = 0,
+  /* PartialGroupByExpression (groupby.cc:231-491): key + saved states */
+  EVQL_MODE_PARTIAL = 1
+} evql_group_mode;
+
+typedef enum {
+  /* FastCSTableScan (CSTableScan.cc:688-1009): one row per record, flat */
+  EVQL_SCAN_FLAT = 0,
+  /* CSTableScan, AggregationStrategy::NO_AGGREGATION (CSTableScan.cc:187-541):
+   * Dremel assembly, one row per leaf repetition */
+  EVQL_SCAN_NESTED = 1
+} evql_scan_mode;
+
+typedef struct {
+  /* SequentialScanNode::selectedColumns(): X_INPUT(i) of `where` and
+   * `scan_select` programs indexes this list */
+  const char* const* scan_columns;
+  const uint32_t* scan_column_types; /* evql_stype per scan column */
+  uint32_t n_scan_columns;
+
+  const evql_program_t* where; /* NULL => no predicate */
+
+  /* scan select list; X_INPUT(j) of group_exprs / select_exprs indexes it */
+  const evql_program_t* scan_select;
+  uint32_t n_scan_select;
+
+  const evql_program_t* group_exprs; /* n_group == 0 => one global group */
+  uint32_t n_group;
+
+  const evql_program_t* select_exprs;
+  uint32_t n_select;
+
+  /* AbstractCSTableScan::setFilter (CSTableScan.h:36-41): bit i == 0 drops
+   * record i.  NULL => no external filter */
+  const uint8_t* row_filter_bits;
+  uint64_t row_filter_len; /* in rows */
+
+  uint32_t group_mode; /* evql_group_mode */
+  uint32_t scan_mode;  /* evql_scan_mode  */
+  uint64_t groups_hint; /* expected number of groups; 0 = unknown */
+
+  /* row range (partition slice) [row_begin, row_end); row_end == 0 => all */
+  uint64_t row_begin;
+  uint64_t row_end;
+} evql_plan_desc_t;
+
+/* Lowers the plan to a fused kernel and compiles it (cached by fingerprint).
+ * Replaces DefaultScheduler::buildGroupByExpression + buildSequentialScan
+ * (sql/scheduler.cc:134-182).  EVQL_ENOTSUP => not lowerable. */
+int evql_query_create(evql_ctx_t* ctx, evql_table_t* table,
+                      const evql_plan_desc_t* plan, evql_query_t** out);
+void evql_query_destroy(evql_query_t* q);
+
+/* txn_->triggerHeartbeat() (transaction.cc:54-60): return non-zero to abort */
+typedef int (*evql_heartbeat_fn)(void* user);
+
+/* TableExpression::execute (table_expression.h:38): runs scan+filter+aggregate
+ * to completion on the device. */
+int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user);
+
+/* asynchronous form used by benchmarks: enqueue the kernels on the context
+ * stream without waiting; evql_query_finish() waits and collects the result. */
+int evql_query_launch(evql_query_t* q);
+int evql_query_finish(evql_query_t* q);
+
+/* TableExpression::getColumnCount / getColumnType (table_expression.h:44-46);
+ * valid right after evql_query_create (ResultCursor sizes its buffers before
+ * execute(), result_cursor.cc:39-42). */
+int evql_query_column_count(const evql_query_t* q);
+int evql_query_column_type(const evql_query_t* q, int idx);
+
+typedef struct {
+  const uint8_t* data; /* packed SVector elements (svalue.cc:410-517) */
+  size_t size;         /* bytes */
+} evql_column_buf_t;
+
+/* TableExpression::nextBatch (table_expression.h:40-42): up to max_rows (the
+ * reference uses kOutputBatchSize = 1024) result rows; cols[i] receive the
+ * packed bytes to SVector::append.  Buffers stay valid until the next call.
+ * *nrows == 0 => EOF (and stays 0). */
+int evql_query_next_batch(evql_query_t* q, size_t max_rows,
+                          evql_column_buf_t* cols, size_t* nrows);
+
+/* statistics of the last execute */
+typedef struct {
+  uint64_t rows_scanned;
+  uint64_t rows_passed;
+  uint64_t num_groups;
+  uint64_t algorithmic_bytes; /* SURVEY 8d B_alg of the columns referenced */
+  double kernel_ms;           /* device time of the dominant (scan) kernel */
+  double total_ms;            /* all kernels of the query                   */
+  uint32_t n_kernel_launches;
+  uint32_t used_lds_table;
+} evql_query_stats_t;
+int evql_query_stats(const evql_query_t* q, evql_query_stats_t* out);
+
+/* the generated HIP source of the fused kernel (inspection / tests) */
+const char* evql_query_kernel_source(const evql_query_t* q);
+
+/* ------------------------------------------------------------------------ */
+/* partial aggregates across partitions / GPUs                                */
+/*   PartialGroupByExpression -> GroupByMergeExpression, groupby.cc:438-615   */
+/* ------------------------------------------------------------------------ */
+
+/* After execute() in EVQL_MODE_PARTIAL the group table stays in HBM as SoA
+ * device arrays: words[w * capacity + slot], w < words_per_group.  Word 0 is
+ * the slot state/identity, the following words the key and aggregate states.
+ * These are what ranks exchange over RCCL. */
+typedef struct {
+  void* device_words;    /* uint64_t[words_per_group * capacity] in HBM */
+  uint64_t capacity;     /* slots */
+  uint32_t words_per_group;
+  uint64_t num_groups;
+} evql_partial_view_t;
+int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out);
+
+/* number of 8-byte words in one exported group record, and compaction of the
+ * table into dense records (record-major) for the wire */
+int evql_query_export_groups(evql_query_t* q, void* device_dst,
+                             uint64_t max_groups, uint64_t* n_groups);
+/* merge dense records produced by evql_query_export_groups on another
+ * partition / rank into this query's table (mergeInstance per aggregate) */
+int evql_query_import_groups(evql_query_t* q, const void* device_src,
+                             uint64_t n_groups);
+uint32_t evql_query_record_words(const evql_query_t* q);
+
+/* ------------------------------------------------------------------------ */
+/* build support                                                              */
+/* ------------------------------------------------------------------------ */
+/* Compile the fused kernel of `plan` for gfx950 without a device (used by
+ * __graft_entry__.build() and the CPU test-suite).  Stores the code object in
+ * the on-disk kernel cache when cache_dir != NULL. */
+int evql_compile_only(const evql_plan_desc_t* plan,
+                      const evql_column_info_t* columns, int ncolumns,
+                      const char* cache_dir, size_t* code_size);
+void evql_set_kernel_cache_dir(const char* dir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVQL_GPU_H */
