@@ -1,0 +1,358 @@
+"""eventql_amd -- MI355X-native scan -> filter -> GROUP BY executor for EventQL
+cstable files, behind the C ABI of include/evql_gpu.h.
+
+This package is a thin ctypes host layer over libevql_mi355x.so (C++/HIP).  It
+never computes results itself: if the library, the HIP device or the kernel
+compiler is missing, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi as K
+from .plan import Plan, unpack_svector  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevql_mi355x.so")
+KERNEL_CACHE_DIR = os.path.join(_HERE, "_kcache")
+
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_f64p = C.POINTER(C.c_double)
+
+
+class EvqlError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (status %d)" % (msg, code))
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def lib():
+    """loads libevql_mi355x.so; raises if it has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libevql_mi355x.so is missing: run `make -C eventql_amd/csrc` "
+            "(or __graft_entry__.build()); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    L.evql_last_error.restype = C.c_char_p
+    L.evql_version.restype = C.c_char_p
+    L.evql_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.evql_ctx_destroy.argtypes = [C.c_void_p]
+    L.evql_ctx_synchronize.argtypes = [C.c_void_p]
+    L.evql_ctx_stream.restype = C.c_void_p
+    L.evql_ctx_stream.argtypes = [C.c_void_p]
+    L.evql_table_open_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.evql_table_open_image.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.evql_table_close.argtypes = [C.c_void_p]
+    L.evql_table_num_rows.restype = C.c_uint64
+    L.evql_table_num_rows.argtypes = [C.c_void_p]
+    L.evql_table_num_columns.argtypes = [C.c_void_p]
+    L.evql_table_column_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(K.ColumnInfo)]
+    L.evql_table_image_size.restype = C.c_uint64
+    L.evql_table_image_size.argtypes = [C.c_void_p]
+    L.evql_table_download_image.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.evql_table_generate.argtypes = [C.c_void_p, C.POINTER(K.SynthSpec), C.POINTER(C.c_void_p)]
+    L.evql_writer_create.argtypes = [C.POINTER(K.ColumnSpec), C.c_int, C.POINTER(C.c_void_p)]
+    L.evql_writer_put_uint.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p, _u64p]
+    L.evql_writer_put_float.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p, _f64p]
+    L.evql_writer_put_string.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p,
+                                         _u64p, C.c_char_p]
+    L.evql_writer_commit.argtypes = [C.c_void_p, C.c_uint64]
+    L.evql_writer_image.restype = C.c_void_p
+    L.evql_writer_image.argtypes = [C.c_void_p, _u64p]
+    L.evql_writer_write_file.argtypes = [C.c_void_p, C.c_char_p]
+    L.evql_writer_destroy.argtypes = [C.c_void_p]
+    L.evql_query_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(K.PlanDesc),
+                                    C.POINTER(C.c_void_p)]
+    L.evql_query_destroy.argtypes = [C.c_void_p]
+    L.evql_query_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.evql_query_launch.argtypes = [C.c_void_p]
+    L.evql_query_finish.argtypes = [C.c_void_p]
+    L.evql_query_column_count.argtypes = [C.c_void_p]
+    L.evql_query_column_type.argtypes = [C.c_void_p, C.c_int]
+    L.evql_query_next_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(K.ColumnBuf),
+                                        C.POINTER(C.c_size_t)]
+    L.evql_query_stats.argtypes = [C.c_void_p, C.POINTER(K.QueryStats)]
+    L.evql_query_kernel_source.restype = C.c_char_p
+    L.evql_query_kernel_source.argtypes = [C.c_void_p]
+    L.evql_query_record_words.restype = C.c_uint32
+    L.evql_query_record_words.argtypes = [C.c_void_p]
+    L.evql_query_partial_view.argtypes = [C.c_void_p, C.POINTER(K.PartialView)]
+    L.evql_query_export_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
+    L.evql_query_import_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.evql_set_kernel_cache_dir.argtypes = [C.c_char_p]
+    L.evql_compile_only.argtypes = [C.POINTER(K.PlanDesc), C.POINTER(K.ColumnInfo), C.c_int,
+                                    C.c_char_p, C.POINTER(C.c_size_t)]
+    L.evql_set_kernel_cache_dir(KERNEL_CACHE_DIR.encode())
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise EvqlError(rc, lib().evql_last_error().decode(errors="replace"))
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+# ---------------------------------------------------------------------------
+# host-side writer
+# ---------------------------------------------------------------------------
+class Writer:
+    """cstable v0.2.0 writer (evql_writer_*).  columns: list of dict(name,
+    logical_type, storage_type, rlevel_max=0, dlevel_max=0, bitpack_max_value=0)"""
+
+    def __init__(self, columns):
+        L = lib()
+        self.columns = columns
+        self._names = [c["name"].encode() for c in columns]
+        specs = (K.ColumnSpec * len(columns))()
+        for i, c in enumerate(columns):
+            specs[i] = K.ColumnSpec(self._names[i], c["logical_type"], c["storage_type"],
+                                    c.get("column_id", i + 1), c.get("rlevel_max", 0),
+                                    c.get("dlevel_max", 0), c.get("bitpack_max_value", 0))
+        self.h = C.c_void_p()
+        _check(L.evql_writer_create(specs, len(columns), C.byref(self.h)))
+        self._index = {c["name"]: i for i, c in enumerate(columns)}
+
+    def put(self, name, values, rlvl=None, dlvl=None, present=None):
+        L = lib()
+        col = self._index[name]
+        kind = self.columns[col]["logical_type"]
+        n = len(values)
+        rl = np.ascontiguousarray(rlvl, np.uint64) if rlvl is not None else None
+        dl = np.ascontiguousarray(dlvl, np.uint64) if dlvl is not None else None
+        pr = np.ascontiguousarray(present, np.uint8) if present is not None else None
+        if kind == K.COL_STRING:
+            off = np.zeros(n + 1, np.uint64)
+            if n:
+                off[1:] = np.cumsum([len(s) for s in values])
+            blob = b"".join(values)
+            _check(L.evql_writer_put_string(self.h, col, n, _ptr(rl, _u64p), _ptr(dl, _u64p),
+                                            _ptr(pr, _u8p), _ptr(off, _u64p), blob))
+        elif kind == K.COL_FLOAT:
+            v = np.ascontiguousarray(values, np.float64)
+            _check(L.evql_writer_put_float(self.h, col, n, _ptr(rl, _u64p), _ptr(dl, _u64p),
+                                           _ptr(pr, _u8p), _ptr(v, _f64p)))
+        else:
+            v = np.ascontiguousarray(values, np.uint64)
+            _check(L.evql_writer_put_uint(self.h, col, n, _ptr(rl, _u64p), _ptr(dl, _u64p),
+                                          _ptr(pr, _u8p), _ptr(v, _u64p)))
+
+    def commit(self, num_rows):
+        _check(lib().evql_writer_commit(self.h, num_rows))
+
+    def image(self):
+        n = C.c_uint64()
+        p = lib().evql_writer_image(self.h, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def write_file(self, path):
+        _check(lib().evql_writer_write_file(self.h, path.encode()))
+
+    def close(self):
+        if self.h:
+            lib().evql_writer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---------------------------------------------------------------------------
+# device objects
+# ---------------------------------------------------------------------------
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _check(lib().evql_ctx_create(device, stream, C.byref(self.h)))
+
+    def synchronize(self):
+        _check(lib().evql_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib().evql_ctx_stream(self.h)
+
+    def open_file(self, path):
+        t = C.c_void_p()
+        _check(lib().evql_table_open_file(self.h, path.encode(), C.byref(t)))
+        return Table(self, t)
+
+    def open_image(self, image):
+        t = C.c_void_p()
+        buf = bytes(image)
+        _check(lib().evql_table_open_image(self.h, buf, len(buf), C.byref(t)))
+        return Table(self, t)
+
+    def generate(self, num_rows, columns="kabv", seed=None, k_mod=1000, u_mod=0, k_bits=0):
+        from . import synth
+        bits = {"k": 1, "a": 2, "b": 4, "v": 8, "u": 16}
+        mask = 0
+        for c in columns:
+            mask |= bits[c]
+        spec = K.SynthSpec(num_rows, synth.SEED if seed is None else seed, k_mod, u_mod, mask,
+                           k_bits)
+        t = C.c_void_p()
+        _check(lib().evql_table_generate(self.h, C.byref(spec), C.byref(t)))
+        return Table(self, t)
+
+    def close(self):
+        if self.h:
+            lib().evql_ctx_destroy(self.h)
+            self.h = None
+
+
+class Table:
+    def __init__(self, ctx, h):
+        self.ctx = ctx
+        self.h = h
+
+    @property
+    def num_rows(self):
+        return lib().evql_table_num_rows(self.h)
+
+    def columns(self):
+        out = []
+        for i in range(lib().evql_table_num_columns(self.h)):
+            ci = K.ColumnInfo()
+            _check(lib().evql_table_column_info(self.h, i, C.byref(ci)))
+            out.append(dict(name=ci.name.decode(), logical_type=ci.logical_type,
+                            storage_type=ci.storage_type, column_id=ci.column_id,
+                            rlevel_max=ci.rlevel_max, dlevel_max=ci.dlevel_max,
+                            n_data_pages=ci.n_data_pages, payload_bytes=ci.payload_bytes))
+        return out
+
+    def schema(self):
+        """column name -> evql_stype as FastCSTableScan would type it"""
+        from .plan import stype_of_column
+        return {c["name"]: stype_of_column(c["logical_type"]) for c in self.columns()
+                if c["logical_type"] != K.COL_SUBRECORD}
+
+    def download_image(self):
+        n = lib().evql_table_image_size(self.h)
+        buf = C.create_string_buffer(n)
+        _check(lib().evql_table_download_image(self.h, buf, n))
+        return buf.raw
+
+    def query(self, plan):
+        q = C.c_void_p()
+        _check(lib().evql_query_create(self.ctx.h, self.h, C.byref(plan.desc), C.byref(q)))
+        return Query(self, plan, q)
+
+    def close(self):
+        if self.h:
+            lib().evql_table_close(self.h)
+            self.h = None
+
+
+class Result:
+    def __init__(self, columns, types, raw):
+        self.columns = columns
+        self.types = types
+        self.raw = raw
+        self.nrows = len(columns[0]) if columns else 0
+
+    def rows(self):
+        return list(zip(*self.columns)) if self.columns else []
+
+
+class Query:
+    """mirrors csql::TableExpression: execute() once, next_batch() until 0 rows"""
+
+    def __init__(self, table, plan, h):
+        self.table = table
+        self.plan = plan  # keeps the ctypes buffers alive
+        self.h = h
+
+    def execute(self):
+        _check(lib().evql_query_execute(self.h, None, None))
+
+    def launch(self):
+        _check(lib().evql_query_launch(self.h))
+
+    def finish(self):
+        _check(lib().evql_query_finish(self.h))
+
+    def column_count(self):
+        return lib().evql_query_column_count(self.h)
+
+    def column_type(self, i):
+        return lib().evql_query_column_type(self.h, i)
+
+    def next_batch(self, max_rows=1024):
+        nc = self.column_count()
+        bufs = (K.ColumnBuf * max(1, nc))()
+        n = C.c_size_t()
+        _check(lib().evql_query_next_batch(self.h, max_rows, bufs, C.byref(n)))
+        raw = [C.string_at(bufs[i].data, bufs[i].size) if bufs[i].size else b""
+               for i in range(nc)]
+        return n.value, raw
+
+    def fetch_all(self, batch=1024):
+        nc = self.column_count()
+        types = [self.column_type(i) for i in range(nc)]
+        raws = [b""] * nc
+        while True:
+            n, raw = self.next_batch(batch)
+            if n == 0:
+                break
+            raws = [a + b for a, b in zip(raws, raw)]
+        cols = [unpack_svector(t, r) for t, r in zip(types, raws)]
+        return Result(cols, types, raws)
+
+    def run(self):
+        self.execute()
+        return self.fetch_all()
+
+    def stats(self):
+        s = K.QueryStats()
+        _check(lib().evql_query_stats(self.h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in K.QueryStats._fields_}
+
+    def kernel_source(self):
+        return lib().evql_query_kernel_source(self.h).decode()
+
+    def record_words(self):
+        return lib().evql_query_record_words(self.h)
+
+    def export_groups(self, device_ptr, max_groups):
+        n = C.c_uint64()
+        _check(lib().evql_query_export_groups(self.h, device_ptr, max_groups, C.byref(n)))
+        return n.value
+
+    def import_groups(self, device_ptr, n):
+        _check(lib().evql_query_import_groups(self.h, device_ptr, n))
+
+    def close(self):
+        if self.h:
+            lib().evql_query_destroy(self.h)
+            self.h = None
+
+
+def compile_only(plan, columns, cache_dir=None):
+    """compile the fused kernel of `plan` for gfx950 without a device.
+    columns: list of dict(name, logical_type, storage_type, dlevel_max=0, bits=0)"""
+    infos = (K.ColumnInfo * len(columns))()
+    for i, c in enumerate(columns):
+        infos[i].name = c["name"].encode()
+        infos[i].logical_type = c["logical_type"]
+        infos[i].storage_type = c["storage_type"]
+        infos[i].column_id = i + 1
+        infos[i].dlevel_max = c.get("dlevel_max", 0)
+        infos[i].rlevel_max = c.get("rlevel_max", 0)
+        infos[i].payload_bytes = c.get("bits", 0)
+    size = C.c_size_t()
+    cd = (cache_dir or KERNEL_CACHE_DIR).encode()
+    _check(lib().evql_compile_only(C.byref(plan.desc), infos, len(columns), cd, C.byref(size)))
+    return size.value

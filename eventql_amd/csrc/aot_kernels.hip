@@ -1,0 +1,429 @@
+// aot_kernels.hip -- ahead-of-time gfx950 kernels (see aot_kernels.h).
+#include "aot_kernels.h"
+#include "evql_device.h"
+
+namespace evql {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ u64 rt_column_value(const u8* image, const RtColumn& c, u64 i) {
+  switch (c.mode) {
+    case 0: return evql_plain64(image, (const u64*) c.pages, i);
+    case 1: return evql_plain32(image, (const u64*) c.pages, i);
+    case 2: return evql_bitpacked_rt(image, (const u64*) c.pages, c.bits, i);
+    default: return c.soa[i];
+  }
+}
+
+// ---- table maintenance -----------------------------------------------------------
+__global__ void k_table_init(TableInitArgs a) {
+  const u64 total = a.stride * a.nwords;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (u64) gridDim.x * blockDim.x) {
+    a.words[i] = a.identity[i / a.stride];
+  }
+}
+
+__global__ void k_table_compact(const u64* words, u64 gcap, u64 stride, u32 nwords,
+                                u64* out, u64 max_records, u64* counter) {
+  const u64 nslots = gcap + 2;
+  for (u64 s = (u64) blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
+       s += (u64) gridDim.x * blockDim.x) {
+    const u64 k = words[s];
+    if (k == EVQL_EMPTY) continue;
+    const u64 idx = atomicAdd(counter, 1ull);
+    if (idx >= max_records) continue;
+    u64* rec = out + idx * (nwords + 1);
+    rec[0] = s == gcap ? 1ull : (s == gcap + 1 ? 2ull : 0ull);
+    rec[1] = s == gcap ? EVQL_EMPTY : k;
+    for (u32 w = 1; w < nwords; ++w) rec[1 + w] = words[(u64) w * stride + s];
+  }
+}
+
+__device__ __forceinline__ void rt_atomic(u32 op, u64* p, u64 v) {
+  switch (op) {
+    case EVQL_OP_ADD_U64: evql_atomic<EVQL_OP_ADD_U64>(p, v); break;
+    case EVQL_OP_ADD_F64: evql_atomic<EVQL_OP_ADD_F64>(p, v); break;
+    case EVQL_OP_MIN_U64: evql_atomic<EVQL_OP_MIN_U64>(p, v); break;
+    case EVQL_OP_MAX_U64: evql_atomic<EVQL_OP_MAX_U64>(p, v); break;
+    case EVQL_OP_MIN_I64: evql_atomic<EVQL_OP_MIN_I64>(p, v); break;
+    case EVQL_OP_MAX_I64: evql_atomic<EVQL_OP_MAX_I64>(p, v); break;
+    case EVQL_OP_MIN_F64: evql_atomic<EVQL_OP_MIN_F64>(p, v); break;
+    case EVQL_OP_MAX_F64: evql_atomic<EVQL_OP_MAX_F64>(p, v); break;
+  }
+}
+
+__global__ void k_table_merge(MergeArgs a, const u64* records, u64 n) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = records + i * (a.nwords + 1);
+    const u64 kind = rec[0], ident = rec[1];
+    i64 gs;
+    if (kind == 1) {
+      gs = (i64) a.gcap;
+      a.words[gs] = 0;
+    } else if (kind == 2) {
+      gs = (i64) a.gcap + 1;
+      a.words[gs] = 0;
+    } else {
+      gs = evql_gtab_find((u64*) a.words, a.gcap, ident, evql_mix64(ident));
+    }
+    if (gs < 0) {
+      atomicOr(&a.status[0], EVQL_ST_TABLE_FULL);
+      continue;
+    }
+    for (u32 w = 1; w < a.nwords; ++w) {
+      rt_atomic(a.ops[w], (u64*) &a.words[(u64) w * a.stride + gs], rec[1 + w]);
+    }
+  }
+}
+
+__global__ void k_gather_rows(const u8* image, const RtColumn* cols, u32 ncols,
+                              const u64* rows, u64 n, u64* out_vals, u8* out_tags) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 r = rows[i];
+    for (u32 c = 0; c < ncols; ++c) {
+      const RtColumn col = cols[c];
+      out_vals[(u64) c * n + i] = rt_column_value(image, col, r);
+      out_tags[(u64) c * n + i] = col.tags ? col.tags[r] : 0;
+    }
+  }
+}
+
+// ---- block-wide helpers -----------------------------------------------------------
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 t = __shfl_up(v, d, 64);
+    if ((int) (threadIdx.x & 63) >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one u32 per thread across a 256-thread block; *total out
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total) {
+  __shared__ u32 wsum[kBlock / 64];
+  const u32 incl = wave_incl_scan(v);
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 off = 0, tot = 0;
+  for (u32 w = 0; w < kBlock / 64; ++w) {
+    if (w < wave) off += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
+  return off + incl - v;
+}
+
+// ---- definition levels -> tags ---------------------------------------------------
+// tile = 2048 rows, 8 consecutive rows per thread
+__global__ void __launch_bounds__(kBlock) k_dlevel_tags(const u8* image, const u64* pages,
+                                                        u32 dbits, u32 dmax, u64 nrows,
+                                                        u8* tags, u64* tile_counts) {
+  const u64 tile = blockIdx.x;
+  const u64 r0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 cnt = 0;
+  u64 packed = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u64 r = r0 + j;
+    u32 tag = 1;
+    if (r < nrows) {
+      const u32 d = evql_bitpacked_rt(image, pages, dbits, r);
+      tag = d == dmax ? 0 : 1;
+      cnt += 1 - tag;
+    }
+    packed |= (u64) tag << (8 * j);
+  }
+  // tags buffer is padded to a tile multiple
+  *reinterpret_cast<u64*>(tags + r0) = packed;
+  u32 total;
+  block_excl_scan(cnt, &total);
+  if (threadIdx.x == 0) tile_counts[tile] = total;
+}
+
+__global__ void __launch_bounds__(1024) k_exclusive_scan(u64* data, u64 n, u64* total) {
+  __shared__ u64 wsum[16];
+  __shared__ u64 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (u64 base = 0; base < n; base += 1024) {
+    const u64 i = base + threadIdx.x;
+    const u64 v = i < n ? data[i] : 0;
+    u64 incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      u32 lo = (u32) incl, hi = (u32) (incl >> 32);
+      lo = __shfl_up(lo, d, 64);
+      hi = __shfl_up(hi, d, 64);
+      if ((int) (threadIdx.x & 63) >= d) incl += (u64) lo | ((u64) hi << 32);
+    }
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u64 off = carry_s, tot = 0;
+    for (u32 w = 0; w < 16; ++w) {
+      if (w < wave) off += wsum[w];
+      tot += wsum[w];
+    }
+    if (i < n) data[i] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+__global__ void __launch_bounds__(kBlock) k_expand_nullable(const u8* image, RtColumn src,
+                                                            const u8* tags,
+                                                            const u64* tile_offsets, u64 nrows,
+                                                            u64* values) {
+  const u64 tile = blockIdx.x;
+  const u64 r0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 packed = *reinterpret_cast<const u64*>(tags + r0);
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += ((packed >> (8 * j)) & 1) ? 0 : (r0 + j < nrows ? 1 : 0);
+  u32 total;
+  u64 idx = tile_offsets[tile] + block_excl_scan(cnt, &total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u64 r = r0 + j;
+    const bool defined = !((packed >> (8 * j)) & 1) && r < nrows;
+    u64 v = 0;
+    if (defined) v = rt_column_value(image, src, idx++);
+    values[r] = v;  // padded to a tile multiple
+  }
+}
+
+// ---- LEB128 -------------------------------------------------------------------------
+__device__ __forceinline__ u8 vbyte(const u8* image, const u64* pages, u64 pos) {
+  return image[pages[pos >> 19] + (pos & 0x7ffffull)];
+}
+
+// chunk = 4096 bytes, 16 bytes per thread
+__global__ void __launch_bounds__(kBlock) k_leb128_count(const u8* image, const u64* pages,
+                                                         u64 nbytes, u64* chunk_counts) {
+  const u64 p0 = (u64) blockIdx.x * kLebChunk + (u64) threadIdx.x * 16;
+  u32 cnt = 0;
+  if (p0 < nbytes) {
+    const u8* p = image + pages[p0 >> 19] + (p0 & 0x7ffffull);
+    const evql_u32x4 q = *reinterpret_cast<const evql_u32x4*>(p);
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt += 4 - __popc(w[k] & 0x80808080u);
+  }
+  u32 total;
+  block_excl_scan(cnt, &total);
+  if (threadIdx.x == 0) chunk_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock) k_leb128_decode(const u8* image, const u64* pages,
+                                                          u64 nbytes, const u64* chunk_offsets,
+                                                          u64 nvalues, u64* values) {
+  const u64 p0 = (u64) blockIdx.x * kLebChunk + (u64) threadIdx.x * 16;
+  u8 b[16];
+  u32 cnt = 0;
+  if (p0 < nbytes) {
+    const u8* p = image + pages[p0 >> 19] + (p0 & 0x7ffffull);
+    const evql_u32x4 q = *reinterpret_cast<const evql_u32x4*>(p);
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      b[k] = (u8) (w[k >> 2] >> (8 * (k & 3)));
+      cnt += (b[k] & 0x80) ? 0 : 1;
+    }
+  }
+  u32 total;
+  u64 idx = chunk_offsets[blockIdx.x] + block_excl_scan(cnt, &total);
+  if (p0 >= nbytes) return;
+  bool prev_term = p0 == 0 ? true : !(vbyte(image, pages, p0 - 1) & 0x80);
+#pragma unroll 1
+  for (int k = 0; k < 16; ++k) {
+    if (prev_term && idx < nvalues) {
+      // a value starts at byte k: decode forward (may leave this thread's bytes)
+      u64 v = 0;
+      for (int i = 0; i < 10; ++i) {
+        const u64 pos = p0 + k + i;
+        const u8 c = (k + i < 16) ? b[k + i] : (pos < nbytes ? vbyte(image, pages, pos) : 0);
+        v |= (u64) (c & 0x7f) << (7 * i);
+        if (!(c & 0x80)) break;
+      }
+      values[idx] = v;
+    }
+    prev_term = !(b[k] & 0x80);
+    if (prev_term) ++idx;
+  }
+}
+
+__global__ void k_string_hash(const u8* image, const u64* pages, const u64* offsets,
+                              const u32* lens, u64 n, u64* out) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 off = offsets[i];
+    const u32 len = lens[i];
+    u64 h = 0xcbf29ce484222325ull ^ ((u64) len * 0x9e3779b97f4a7c15ull);
+    for (u32 k = 0; k < len; ++k) {
+      h ^= vbyte(image, pages, off + k);
+      h *= 0x100000001b3ull;
+    }
+    out[i] = evql_mix64(h);
+  }
+}
+
+// ---- synthetic table -----------------------------------------------------------------
+// one thread generates 128 consecutive rows (= one bit-packed block)
+__global__ void __launch_bounds__(kBlock) k_synth(const SynthArgs* ap, u64 nchunks) {
+  const SynthArgs& a = *ap;
+  const u64 chunk = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (chunk >= nchunks) return;
+  const u64 r0 = chunk * 128;
+  // x = M^(r0) seed by binary decomposition over the precomputed M^(2^j)
+  u64 x = a.seed;
+  for (int j = 0; j < 48; ++j) {
+    if (!((r0 >> j) & 1)) continue;
+    u64 y = 0;
+    const u64* m = (const u64*) a.jump[j];
+    for (int bit = 0; bit < 64; ++bit) {
+      if ((x >> bit) & 1) y ^= m[bit];
+    }
+    x = y;
+  }
+  const u32 kb = a.k_bits;
+  for (u32 i = 0; i < 128; ++i) {
+    const u64 r = r0 + i;
+    if (r >= a.num_rows) break;
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    if (a.columns & 1u) {
+      const u64 k = x % a.k_mod;
+      if (kb == 0) {
+        *reinterpret_cast<u64*>(a.image + a.off_k + r * 8) = k;
+      } else {
+        // libsimdcomp layout; the image is zero-initialised
+        u32* W = reinterpret_cast<u32*>(a.image + a.off_k + 4 + chunk * (u64) (16 * kb));
+        const u32 l = i & 3u, kk = i >> 2, p = kk * kb, w = p >> 5, s = p & 31u;
+        atomicOr(&W[4 * w + l], (u32) (k << s));
+        if (s + kb > 32) atomicOr(&W[4 * (w + 1) + l], (u32) (k >> (32 - s)));
+      }
+    }
+    if (a.columns & 2u) *reinterpret_cast<u64*>(a.image + a.off_a + r * 8) = (x >> 8) & 0xffffull;
+    if (a.columns & 4u) *reinterpret_cast<u64*>(a.image + a.off_b + r * 8) = (x >> 24) & 0xffffull;
+    if (a.columns & 8u) {
+      *reinterpret_cast<double*>(a.image + a.off_v + r * 8) = (double) (x >> 40) / 1024.0;
+    }
+    if (a.columns & 16u) *reinterpret_cast<u64*>(a.image + a.off_u + r * 8) = x % a.u_mod;
+  }
+}
+
+inline int grid_for(u64 n, int block = kBlock, int cap = 8192) {
+  u64 g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (u64) cap) g = cap;
+  return (int) g;
+}
+
+}  // namespace
+
+hipError_t launch_table_init(const TableInitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_table_init, dim3(grid_for(a.stride * a.nwords)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_table_compact(const uint64_t* words, uint64_t gcap, uint64_t stride,
+                                uint32_t nwords, uint64_t* out_records, uint64_t max_records,
+                                uint64_t* counter, hipStream_t s) {
+  hipLaunchKernelGGL(k_table_compact, dim3(grid_for(gcap + 2)), dim3(kBlock), 0, s,
+                     (const u64*) words, (u64) gcap, (u64) stride, nwords, (u64*) out_records,
+                     (u64) max_records, (u64*) counter);
+  return hipGetLastError();
+}
+
+hipError_t launch_table_merge(const MergeArgs& a, const uint64_t* records, uint64_t n,
+                              hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_table_merge, dim3(grid_for(n)), dim3(kBlock), 0, s, a,
+                     (const u64*) records, (u64) n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const uint8_t* image, const RtColumn* d_cols, uint32_t ncols,
+                              const uint64_t* d_rows, uint64_t n, uint64_t* out_vals,
+                              uint8_t* out_tags, hipStream_t s) {
+  if (n == 0 || ncols == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n)), dim3(kBlock), 0, s, image, d_cols, ncols,
+                     (const u64*) d_rows, (u64) n, (u64*) out_vals, out_tags);
+  return hipGetLastError();
+}
+
+hipError_t launch_dlevel_tags(const uint8_t* image, const uint64_t* dlevel_pages, uint32_t dbits,
+                              uint32_t dmax, uint64_t nrows, uint8_t* tags,
+                              uint64_t* tile_counts, hipStream_t s) {
+  const u64 ntiles = (nrows + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dlevel_tags, dim3((unsigned) ntiles), dim3(kBlock), 0, s, image,
+                     (const u64*) dlevel_pages, dbits, dmax, (u64) nrows, tags,
+                     (u64*) tile_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_exclusive_scan(uint64_t* data, uint64_t n, uint64_t* total, hipStream_t s) {
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, (u64*) data, (u64) n,
+                     (u64*) total);
+  return hipGetLastError();
+}
+
+hipError_t launch_expand_nullable(const uint8_t* image, RtColumn src, const uint8_t* tags,
+                                  const uint64_t* tile_offsets, uint64_t nrows,
+                                  uint64_t* values, hipStream_t s) {
+  const u64 ntiles = (nrows + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_expand_nullable, dim3((unsigned) ntiles), dim3(kBlock), 0, s, image, src,
+                     tags, (const u64*) tile_offsets, (u64) nrows, (u64*) values);
+  return hipGetLastError();
+}
+
+hipError_t launch_leb128_count(const uint8_t* image, const uint64_t* pages, uint64_t nbytes,
+                               uint64_t* chunk_counts, hipStream_t s) {
+  const u64 nchunks = (nbytes + kLebChunk - 1) / kLebChunk;
+  if (nchunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_leb128_count, dim3((unsigned) nchunks), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (u64) nbytes, (u64*) chunk_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_leb128_decode(const uint8_t* image, const uint64_t* pages, uint64_t nbytes,
+                                const uint64_t* chunk_offsets, uint64_t nvalues,
+                                uint64_t* values, hipStream_t s) {
+  const u64 nchunks = (nbytes + kLebChunk - 1) / kLebChunk;
+  if (nchunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_leb128_decode, dim3((unsigned) nchunks), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (u64) nbytes, (const u64*) chunk_offsets, (u64) nvalues,
+                     (u64*) values);
+  return hipGetLastError();
+}
+
+hipError_t launch_string_hash(const uint8_t* image, const uint64_t* pages,
+                              const uint64_t* offsets, const uint32_t* lens, uint64_t n,
+                              uint64_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_string_hash, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (const u64*) offsets, lens, (u64) n, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth(const SynthArgs* d_args, uint64_t num_rows, hipStream_t s) {
+  const u64 nchunks = (num_rows + 127) / 128;
+  if (nchunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_synth, dim3((unsigned) ((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     s, d_args, (u64) nchunks);
+  return hipGetLastError();
+}
+
+}  // namespace evql

@@ -1,0 +1,69 @@
+// codegen.h -- plan analysis and HIP source generation for the fused
+// scan -> filter -> GROUP BY kernel ("csql::VM bytecode lowered to fused HIP
+// kernels", BASELINE.json north_star).
+#pragma once
+#include <string>
+#include <vector>
+#include "cstable_format.h"
+#include "plan_ir.h"
+
+namespace evql {
+
+// how the fused kernel reads one scan column
+struct ColAccess {
+  enum Mode { PLAIN64 = 0, PLAIN32 = 1, BITPACKED = 2, SOA = 3 };
+  std::string name;
+  uint32_t stype = EVQL_T_NIL;  // evql_stype seen by the VM
+  Mode mode = PLAIN64;
+  uint32_t bits = 0;          // BITPACKED width
+  bool has_tags = false;      // SOA with a tag byte array (nullable column)
+  bool bool_normalize = false;  // BOOLEAN column: value = (raw > 0)
+  bool from_uint_to_float = false;  // FLOAT64 stype over a uint column: (double) u
+  bool string_hash = false;   // STRING column materialised as hash64
+  int layout_index = -1;      // index into TableLayout::columns
+};
+
+// one 8-byte aggregate state word
+struct StateWord {
+  int op;  // EVQL_OP_* (evql_device.h)
+};
+
+struct AggPlan {
+  uint32_t fn = EVQL_AGG_NONE;
+  ExprPtr arg;         // over scan columns; null for count
+  int first_word = 0;  // index into state words
+  int nwords = 0;
+};
+
+enum KeyMode {
+  KEY_NONE = 0,    // no GROUP BY: one global group, register accumulators
+  KEY_EXACT = 1,   // one fixed-width key: identity = value bits (+ NULL slot)
+  KEY_HASHED = 2   // several keys / string keys: identity = 64-bit tuple hash
+};
+
+struct KernelPlan {
+  std::vector<ColAccess> cols;
+  ExprPtr where;                // over scan columns, may be null
+  std::vector<ExprPtr> group;   // over scan columns
+  std::vector<AggPlan> aggs;    // one per aggregate select expression
+  std::vector<StateWord> states;
+  KeyMode key_mode = KEY_NONE;
+  bool need_first_row = false;
+  bool has_row_filter = false;
+  // slot layout: word 0 identity, [word 1 first_row], then states
+  int words_per_slot() const { return 1 + (need_first_row ? 1 : 0) + int(states.size()); }
+  int state_word_base() const { return 1 + (need_first_row ? 1 : 0); }
+  // launch shape
+  int block = 256;
+  int unroll = 4;
+  int lds_slots = 0;  // 0 => aggregate straight into the HBM table
+  int tile_rows() const { return block * 2 * unroll; }
+};
+
+// the generated translation unit (device library excluded)
+std::string generate_kernel_source(const KernelPlan& kp);
+
+// the embedded text of evql_device.h
+const char* device_library_source();
+
+}  // namespace evql

@@ -1,0 +1,271 @@
+// evql_device.h -- device-side building blocks of the fused
+// scan -> filter -> GROUP BY kernels (gfx950 / CDNA4, wave64).
+//
+// This text is embedded into libevql_mi355x.so and prepended to every
+// plan-specific kernel that codegen.cc emits; the result is compiled with
+// hiprtc for gfx950.  It is also compiled ahead of time as part of
+// aot_kernels.hip (decode / compaction / gather kernels).
+//
+// Reference semantics implemented here:
+//   bit-packed pages      io/cstable/columns/page_reader_bitpacked.cc:30-111 +
+//                         libsimdcomp 4-lane vertical layout (simdbitpacking.c)
+//   plain pages           page_reader_uint64.cc:50-70, page_reader_uint32.cc,
+//                         page_reader_ieee754.cc:38-59
+//   group table           replaces std::unordered_map<SHA1Hash, Vector<void*>>
+//                         of GroupByExpression (groupby.h:54-62)
+//   aggregate states      expressions/aggregate.cc:35-219 (count, sum) and the
+//                         build-supplied sum_float64/min/max/mean
+#ifndef EVQL_DEVICE_H
+#define EVQL_DEVICE_H
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int u32;
+typedef unsigned char u8;
+
+#define EVQL_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define EVQL_MAX_COLS 16
+#define EVQL_WAVE 64
+
+// status bits written by kernels, read by the host after the launch
+#define EVQL_ST_DIV_BY_ZERO 1u
+#define EVQL_ST_TABLE_FULL 2u
+#define EVQL_ST_MOD_BY_ZERO 4u
+
+// all fields are 8 bytes wide so that host and device agree on the layout
+struct EvqlColArg {
+  const u64* pages;  // device array: byte offset of each data page in `image`
+  const u64* soa;    // pre-decoded values (one u64 per row) or NULL
+  const u8* tags;    // pre-decoded tag bytes (STAG_NULL) per row or NULL
+  u64 npages;
+};
+
+struct EvqlArgs {
+  const u8* image;  // cstable file image in HBM
+  u64 row_begin;
+  u64 row_end;
+  u64 ntiles;      // number of row tiles covering [row_begin,row_end)
+  u64 tile0;       // index of the first tile (absolute row / TILE_ROWS)
+  const u8* row_filter;  // bit i == 0 drops row i; NULL = none
+  u64 row_filter_len;
+  u64* gtab;       // global group table: word w of slot s at gtab[w*gcap + s]
+  u64 gcap;        // slots (power of two); two extra special slots follow
+  u32* status;     // [0] error bits, [1] reserved
+  u64* counters;   // [0] rows passed, [1] rows aggregated via LDS overflow
+  EvqlColArg col[EVQL_MAX_COLS];
+};
+
+// ---------------------------------------------------------------------------
+// hashing: slot placement only (identity is the full 64-bit word)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 evql_mix64(u64 x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+__device__ __forceinline__ u64 evql_hash_combine(u64 h, u64 v) {
+  return evql_mix64(h ^ (v + 0x9e3779b97f4a7c15ULL + (h << 6) + (h >> 2)));
+}
+
+// ---------------------------------------------------------------------------
+// column page access.  Pages are only guaranteed 4-byte aligned in the file
+// (a bit-packed page is 4 + 16*b*1024 bytes), so vector loads are declared
+// with 4-byte alignment; gfx950 global loads need dword alignment only.
+// ---------------------------------------------------------------------------
+typedef u32 evql_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef u32 evql_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+
+// two consecutive 8-byte values (rows r, r+1; r even) of a PLAIN u64/f64 column
+__device__ __forceinline__ void evql_plain64_x2(const u8* image, const u64* pages,
+                                                u64 r, u64& v0, u64& v1) {
+  const u8* p = image + pages[r >> 16] + ((r & 0xffffull) << 3);
+  evql_u32x4 q = *reinterpret_cast<const evql_u32x4*>(p);
+  v0 = (u64) q.x | ((u64) q.y << 32);
+  v1 = (u64) q.z | ((u64) q.w << 32);
+}
+
+__device__ __forceinline__ u64 evql_plain64(const u8* image, const u64* pages, u64 r) {
+  const u8* p = image + pages[r >> 16] + ((r & 0xffffull) << 3);
+  evql_u32x2 q = *reinterpret_cast<const evql_u32x2*>(p);
+  return (u64) q.x | ((u64) q.y << 32);
+}
+
+// UINT32_PLAIN: 131072 values per 512 KiB page
+__device__ __forceinline__ void evql_plain32_x2(const u8* image, const u64* pages,
+                                                u64 r, u64& v0, u64& v1) {
+  const u8* p = image + pages[r >> 17] + ((r & 0x1ffffull) << 2);
+  evql_u32x2 q = *reinterpret_cast<const evql_u32x2*>(p);
+  v0 = q.x;
+  v1 = q.y;
+}
+
+__device__ __forceinline__ u64 evql_plain32(const u8* image, const u64* pages, u64 r) {
+  const u8* p = image + pages[r >> 17] + ((r & 0x1ffffull) << 2);
+  return *reinterpret_cast<const u32*>(p);
+}
+
+// pre-decoded SoA column
+__device__ __forceinline__ void evql_soa_x2(const u64* soa, u64 r, u64& v0, u64& v1) {
+  const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(soa + r);
+  v0 = q.x;
+  v1 = q.y;
+}
+
+// value i of a bit-packed stream of width B (compile-time), libsimdcomp layout:
+// block of 128 values = 16*B bytes; value i7: lane l = i7 & 3, k = i7 >> 2,
+// bit position p = k*B inside the lane stream; lane word w sits at u32 index
+// 4*w + l.  The first page carries a 4-byte max_value header.
+template <int B>
+__device__ __forceinline__ u32 evql_bitpacked(const u8* image, const u64* pages, u64 i) {
+  if (B == 0) return 0;
+  const u64 page = i >> 17;  // 1024 blocks * 128 values
+  const u32 j = (u32) (i & 0x1ffffull);
+  const u8* base = image + pages[page] + (page == 0 ? 4 : 0) + (u64) (j >> 7) * (16 * B);
+  const u32 i7 = j & 127u, l = i7 & 3u, k = i7 >> 2;
+  const u32 p = k * B, w = p >> 5, s = p & 31u;
+  const u32* W = reinterpret_cast<const u32*>(base);
+  u64 v = (u64) W[4 * w + l] >> s;
+  if (s + B > 32) v |= (u64) W[4 * (w + 1) + l] << (32 - s);
+  return (u32) (v & (B >= 32 ? 0xffffffffull : ((1ull << (B & 31)) - 1)));
+}
+
+// runtime-width variant (decode kernels)
+__device__ __forceinline__ u32 evql_bitpacked_rt(const u8* image, const u64* pages,
+                                                 u32 B, u64 i) {
+  if (B == 0) return 0;
+  const u64 page = i >> 17;
+  const u32 j = (u32) (i & 0x1ffffull);
+  const u8* base = image + pages[page] + (page == 0 ? 4 : 0) + (u64) (j >> 7) * (16 * B);
+  const u32 i7 = j & 127u, l = i7 & 3u, k = i7 >> 2;
+  const u32 p = k * B, w = p >> 5, s = p & 31u;
+  const u32* W = reinterpret_cast<const u32*>(base);
+  u64 v = (u64) W[4 * w + l] >> s;
+  if (s + B > 32) v |= (u64) W[4 * (w + 1) + l] << (32 - s);
+  return (u32) (v & (B >= 32 ? 0xffffffffull : ((1ull << B) - 1)));
+}
+
+__device__ __forceinline__ bool evql_row_filter(const u8* bits, u64 len, u64 row) {
+  return row < len && ((bits[row >> 3] >> (row & 7)) & 1);
+}
+
+__device__ __forceinline__ double evql_as_f64(u64 v) { return __longlong_as_double((i64) v); }
+__device__ __forceinline__ u64 evql_f64_bits(double v) { return (u64) __double_as_longlong(v); }
+
+// ---------------------------------------------------------------------------
+// aggregate state update primitives.  OP codes are shared with the host
+// (codegen.cc / runtime.cc):
+// ---------------------------------------------------------------------------
+#define EVQL_OP_ADD_U64 0
+#define EVQL_OP_ADD_F64 1
+#define EVQL_OP_MIN_U64 2
+#define EVQL_OP_MAX_U64 3
+#define EVQL_OP_MIN_I64 4
+#define EVQL_OP_MAX_I64 5
+#define EVQL_OP_MIN_F64 6
+#define EVQL_OP_MAX_F64 7
+
+template <int OP>
+__device__ __forceinline__ u64 evql_op_identity() {
+  switch (OP) {
+    case EVQL_OP_MIN_U64: return 0xFFFFFFFFFFFFFFFFull;
+    case EVQL_OP_MAX_U64: return 0ull;
+    case EVQL_OP_MIN_I64: return 0x7FFFFFFFFFFFFFFFull;
+    case EVQL_OP_MAX_I64: return 0x8000000000000000ull;
+    case EVQL_OP_MIN_F64: return 0x7FF0000000000000ull;  // +inf
+    case EVQL_OP_MAX_F64: return 0xFFF0000000000000ull;  // -inf
+    default: return 0ull;
+  }
+}
+
+// plain (non-atomic) combine, used for register accumulators and reductions
+template <int OP>
+__device__ __forceinline__ u64 evql_combine(u64 a, u64 b) {
+  switch (OP) {
+    case EVQL_OP_ADD_U64: return a + b;
+    case EVQL_OP_ADD_F64: return evql_f64_bits(evql_as_f64(a) + evql_as_f64(b));
+    case EVQL_OP_MIN_U64: return a < b ? a : b;
+    case EVQL_OP_MAX_U64: return a > b ? a : b;
+    case EVQL_OP_MIN_I64: return (i64) a < (i64) b ? a : b;
+    case EVQL_OP_MAX_I64: return (i64) a > (i64) b ? a : b;
+    case EVQL_OP_MIN_F64: return evql_as_f64(b) < evql_as_f64(a) ? b : a;
+    case EVQL_OP_MAX_F64: return evql_as_f64(b) > evql_as_f64(a) ? b : a;
+  }
+  return a;
+}
+
+// atomic combine into LDS or global memory (address space is inferred by the
+// compiler after inlining: ds_* for LDS, global_atomic_* for HBM)
+template <int OP>
+__device__ __forceinline__ void evql_atomic(u64* p, u64 v) {
+  switch (OP) {
+    case EVQL_OP_ADD_U64: atomicAdd(p, v); break;
+    case EVQL_OP_ADD_F64: unsafeAtomicAdd(reinterpret_cast<double*>(p), evql_as_f64(v)); break;
+    case EVQL_OP_MIN_U64: atomicMin(p, v); break;
+    case EVQL_OP_MAX_U64: atomicMax(p, v); break;
+    case EVQL_OP_MIN_I64: atomicMin(reinterpret_cast<i64*>(p), (i64) v); break;
+    case EVQL_OP_MAX_I64: atomicMax(reinterpret_cast<i64*>(p), (i64) v); break;
+    case EVQL_OP_MIN_F64: unsafeAtomicMin(reinterpret_cast<double*>(p), evql_as_f64(v)); break;
+    case EVQL_OP_MAX_F64: unsafeAtomicMax(reinterpret_cast<double*>(p), evql_as_f64(v)); break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// open-addressed group table: word 0 of every slot is the 64-bit identity
+// (EVQL_EMPTY = free), claimed with a 64-bit compare-and-swap.
+// ---------------------------------------------------------------------------
+
+// LDS table: returns the slot or -1 when no slot was found within MAXP probes
+template <int MAXP>
+__device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32 h) {
+  u32 s = h & mask;
+#pragma unroll 1
+  for (int probe = 0; probe < MAXP; ++probe) {
+    u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);
+    if (cur == ident) return (int) s;
+    if (cur == EVQL_EMPTY) {
+      u64 old = atomicCAS(&keys[s], EVQL_EMPTY, ident);
+      if (old == EVQL_EMPTY || old == ident) return (int) s;
+    }
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+// global (HBM) table.  Keys never change once written, so a stale plain read
+// can only observe EMPTY, which the CAS then corrects.
+__device__ __forceinline__ i64 evql_gtab_find(u64* keys, u64 cap, u64 ident, u64 h) {
+  const u64 mask = cap - 1;
+  u64 s = h & mask;
+#pragma unroll 1
+  for (u64 probe = 0; probe < cap; ++probe) {
+    u64 cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == ident) return (i64) s;
+    if (cur == EVQL_EMPTY) {
+      u64 old = atomicCAS(&keys[s], EVQL_EMPTY, ident);
+      if (old == EVQL_EMPTY || old == ident) return (i64) s;
+    }
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+// 64-bit wave shuffle
+__device__ __forceinline__ u64 evql_shfl_xor(u64 v, int m) {
+  u32 lo = (u32) v, hi = (u32) (v >> 32);
+  lo = __shfl_xor(lo, m, 64);
+  hi = __shfl_xor(hi, m, 64);
+  return (u64) lo | ((u64) hi << 32);
+}
+
+template <int OP>
+__device__ __forceinline__ u64 evql_wave_reduce(u64 v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = evql_combine<OP>(v, evql_shfl_xor(v, m));
+  return v;
+}
+
+#endif  // EVQL_DEVICE_H

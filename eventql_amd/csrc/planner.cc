@@ -1,0 +1,313 @@
+// planner.cc -- from evql_plan_desc_t (bytecode of the reference's operators)
+// to a KernelPlan: which pages each column is read from, the inlined
+// predicate / key / aggregate-argument expressions and the group-table layout.
+//
+// Mirrors the plan shape the reference builds for
+//   GroupByExpression(select_exprs, group_exprs, FastCSTableScan(stmt))
+// (sql/scheduler.cc:134-182): scan-level programs index scan columns,
+// group-level programs index the scan's select list.
+#include <cstring>
+#include "runtime.h"
+
+namespace evql {
+
+namespace {
+
+// replace INPUT(j) by a copy of sub[j]
+ExprPtr inline_inputs(const ExprPtr& e, const std::vector<ExprPtr>& sub, std::string* err) {
+  if (!e) return e;
+  if (e->kind == Expr::INPUT) {
+    if (e->input >= sub.size()) {
+      *err = "invalid input index";
+      return e;
+    }
+    return sub[e->input];
+  }
+  auto c = std::make_shared<Expr>(*e);
+  for (auto& a : c->args) a = inline_inputs(a, sub, err);
+  return c;
+}
+
+bool has_agg_get(const ExprPtr& e) {
+  if (!e) return false;
+  if (e->kind == Expr::AGG_GET) return true;
+  for (const auto& a : e->args) {
+    if (has_agg_get(a)) return true;
+  }
+  return false;
+}
+
+bool has_input(const ExprPtr& e) {
+  if (!e) return false;
+  if (e->kind == Expr::INPUT) return true;
+  for (const auto& a : e->args) {
+    if (has_input(a)) return true;
+  }
+  return false;
+}
+
+bool is_bare_input(const ExprPtr& e) { return e && e->kind == Expr::INPUT; }
+
+// strings may only flow through untouched (bare column refs)
+bool strings_only_bare(const ExprPtr& e) {
+  if (!e) return true;
+  if (e->kind == Expr::INPUT) return true;
+  if (e->type == EVQL_T_STRING) return false;
+  for (const auto& a : e->args) {
+    if (a->type == EVQL_T_STRING) return false;
+    if (!strings_only_bare(a)) return false;
+  }
+  return true;
+}
+
+int op_for_minmax(uint32_t fn) {
+  switch (fn) {
+    case EVQL_AGG_MIN_UINT64: return 2;
+    case EVQL_AGG_MAX_UINT64: return 3;
+    case EVQL_AGG_MIN_INT64: return 4;
+    case EVQL_AGG_MAX_INT64: return 5;
+    case EVQL_AGG_MIN_FLOAT64: return 6;
+    case EVQL_AGG_MAX_FLOAT64: return 7;
+  }
+  return 0;
+}
+
+}  // namespace
+
+Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan,
+                         evql_query* q, bool* unsupported) {
+  *unsupported = false;
+  KernelPlan& kp = q->kp;
+  auto unsup = [&](const std::string& m) {
+    *unsupported = true;
+    return Status::error(EVQL_ENOTSUP, m);
+  };
+
+  if (plan->scan_mode != EVQL_SCAN_FLAT) return unsup("nested scans are not lowered yet");
+  if (plan->n_scan_columns > EVQL_MAX_COLS_HOST) return unsup("too many scan columns");
+  if (plan->n_select == 0) return unsup("bare scans are not lowered (no GROUP BY / aggregate)");
+
+  // ---- scan columns --------------------------------------------------------------
+  for (uint32_t i = 0; i < plan->n_scan_columns; ++i) {
+    ColAccess c;
+    c.name = plan->scan_columns[i];
+    c.stype = plan->scan_column_types[i];
+    const ColumnLayout* cl = nullptr;
+    for (size_t k = 0; k < layout.columns.size(); ++k) {
+      if (layout.columns[k].name == c.name) {
+        cl = &layout.columns[k];
+        c.layout_index = int(k);
+      }
+    }
+    if (!cl) {
+      // the reference would dereference a null reader here (CSTableScan.cc:747-751)
+      return Status::error(EVQL_EARG, "column not found: " + c.name);
+    }
+    if (cl->rlevel_max > 0) return unsup("repeated column in a flat scan: " + c.name);
+    switch (c.stype) {
+      case EVQL_T_NIL:
+        return Status::error(EVQL_EARG, "illegal column type: NIL");
+      case EVQL_T_INT64:  // CSTableScan.cc:783-784
+        return Status::error(EVQL_EARG, "illegal column type: INT64");
+      default:
+        break;
+    }
+    const bool is_uintish = cl->logical_type == ColumnType::UNSIGNED_INT ||
+                            cl->logical_type == ColumnType::DATETIME ||
+                            cl->logical_type == ColumnType::BOOLEAN;
+    if (c.stype == EVQL_T_STRING) {
+      if (cl->logical_type != ColumnType::STRING) return unsup("string view of a non-string column");
+      c.mode = ColAccess::SOA;
+      c.string_hash = true;
+      c.has_tags = true;
+    } else if (cl->logical_type == ColumnType::STRING) {
+      return unsup("numeric view of a string column");
+    } else if (c.stype == EVQL_T_FLOAT64) {
+      if (cl->logical_type == ColumnType::FLOAT) {
+        c.mode = ColAccess::PLAIN64;
+      } else if (is_uintish) {
+        c.from_uint_to_float = true;  // UnsignedIntColumnReader::readFloat casts
+      } else {
+        return unsup("unsupported column type");
+      }
+    } else {
+      if (cl->logical_type == ColumnType::FLOAT) return unsup("integer view of a float column");
+      if (!is_uintish) return unsup("unsupported column type");
+      // readBoolean = value > 0 (column_reader_uint.cc:78-90)
+      c.bool_normalize = c.stype == EVQL_T_BOOL;
+    }
+    if (!c.string_hash) {
+      switch (cl->storage_type) {
+        case ColumnEncoding::UINT64_PLAIN:
+        case ColumnEncoding::FLOAT_IEEE754:
+          c.mode = ColAccess::PLAIN64;
+          break;
+        case ColumnEncoding::UINT32_PLAIN:
+          c.mode = ColAccess::PLAIN32;
+          break;
+        case ColumnEncoding::UINT32_BITPACKED:
+        case ColumnEncoding::BOOLEAN_BITPACKED:
+          c.mode = ColAccess::BITPACKED;
+          c.bits = 0;  // filled in by the runtime from the page header
+          break;
+        case ColumnEncoding::UINT64_LEB128:
+          c.mode = ColAccess::SOA;
+          break;
+        default:
+          return unsup("unsupported column encoding");
+      }
+      if (cl->dlevel_max > 0) {
+        c.mode = ColAccess::SOA;  // nullable: decoded to values + tags first
+        c.has_tags = true;
+      }
+    }
+    kp.cols.push_back(c);
+  }
+
+  // ---- programs ----------------------------------------------------------------------
+  bool u = false;
+  std::string err;
+  if (plan->where) {
+    err = lower_program(*plan->where, &q->where, &u);
+    if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
+    if (q->where.is_aggregate || q->where.return_type != EVQL_T_BOOL) {
+      return Status::error(EVQL_EARG, "WHERE must be a non-aggregate boolean expression");
+    }
+    if (expr_uses_strings(q->where.call)) return unsup("string predicates are not lowered yet");
+    q->has_where = true;
+    kp.where = q->where.call;
+  }
+  q->scan_select.resize(plan->n_scan_select);
+  std::vector<ExprPtr> scan_out;
+  for (uint32_t i = 0; i < plan->n_scan_select; ++i) {
+    err = lower_program(plan->scan_select[i], &q->scan_select[i], &u);
+    if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
+    if (q->scan_select[i].is_aggregate) return unsup("aggregate in the scan select list");
+    if (!strings_only_bare(q->scan_select[i].call)) return unsup("string expressions are not lowered yet");
+    scan_out.push_back(q->scan_select[i].call);
+  }
+  q->group.resize(plan->n_group);
+  for (uint32_t i = 0; i < plan->n_group; ++i) {
+    err = lower_program(plan->group_exprs[i], &q->group[i], &u);
+    if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
+    if (q->group[i].is_aggregate) return Status::error(EVQL_EARG, "aggregate in GROUP BY");
+    ExprPtr g = inline_inputs(q->group[i].call, scan_out, &err);
+    if (!err.empty()) return Status::error(EVQL_EARG, err);
+    if (!strings_only_bare(g)) return unsup("string expressions are not lowered yet");
+    kp.group.push_back(g);
+  }
+  if (plan->n_group == 0) {
+    kp.key_mode = KEY_NONE;
+  } else if (plan->n_group == 1 && kp.group[0]->type != EVQL_T_STRING &&
+             kp.group[0]->type != EVQL_T_NIL) {
+    kp.key_mode = KEY_EXACT;
+  } else {
+    kp.key_mode = KEY_HASHED;
+  }
+
+  q->select.resize(plan->n_select);
+  q->select_agg_index.assign(plan->n_select, -1);
+  q->select_passthrough.assign(plan->n_select, false);
+  kp.need_first_row = false;
+  for (uint32_t i = 0; i < plan->n_select; ++i) {
+    LoweredProgram& lp = q->select[i];
+    err = lower_program(plan->select_exprs[i], &lp, &u);
+    if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
+    if (lp.is_aggregate) {
+      AggPlan a;
+      a.fn = lp.aggregate_fn;
+      if (a.fn != EVQL_AGG_COUNT) {
+        if (lp.acc_args.size() != 1) return Status::error(EVQL_EARG, "aggregate arity");
+        a.arg = inline_inputs(lp.acc_args[0], scan_out, &err);
+        if (!err.empty()) return Status::error(EVQL_EARG, err);
+        if (expr_uses_strings(a.arg)) return unsup("string aggregates are not lowered");
+      } else if (lp.acc_args.size() == 1 && lp.acc_args[0]->kind == Expr::CALL &&
+                 lp.acc_args[0]->family == EVQL_FAM_TO_NIL) {
+        // count(x): evaluate x for its side effects (division by zero) only when
+        // it is not a plain column / literal
+        const ExprPtr& inner = lp.acc_args[0]->args[0];
+        if (inner->kind == Expr::CALL || inner->kind == Expr::IF) {
+          if (expr_uses_strings(inner)) return unsup("string expressions are not lowered yet");
+        }
+      }
+      a.first_word = int(kp.states.size());
+      switch (a.fn) {
+        case EVQL_AGG_COUNT:
+        case EVQL_AGG_SUM_UINT64:
+        case EVQL_AGG_SUM_INT64:
+          kp.states.push_back({0});
+          a.nwords = 1;
+          break;
+        case EVQL_AGG_SUM_FLOAT64:
+          kp.states.push_back({1});
+          a.nwords = 1;
+          break;
+        case EVQL_AGG_MIN_UINT64:
+        case EVQL_AGG_MAX_UINT64:
+        case EVQL_AGG_MIN_INT64:
+        case EVQL_AGG_MAX_INT64:
+        case EVQL_AGG_MIN_FLOAT64:
+        case EVQL_AGG_MAX_FLOAT64:
+          kp.states.push_back({op_for_minmax(a.fn)});
+          kp.states.push_back({0});
+          a.nwords = 2;
+          break;
+        case EVQL_AGG_MEAN_UINT64:
+        case EVQL_AGG_MEAN_INT64:
+        case EVQL_AGG_MEAN_FLOAT64:
+          kp.states.push_back({1});
+          kp.states.push_back({0});
+          a.nwords = 2;
+          break;
+        default:
+          return unsup("aggregate function not lowerable");
+      }
+      q->select_agg_index[i] = int(kp.aggs.size());
+      kp.aggs.push_back(a);
+      // post-aggregate arithmetic that also reads group-level inputs needs the
+      // group's first row
+      if (has_input(lp.call)) kp.need_first_row = true;
+    } else {
+      if (has_agg_get(lp.call)) return Status::error(EVQL_EARG, "malformed aggregate program");
+      ExprPtr e = inline_inputs(lp.call, scan_out, &err);
+      if (!err.empty()) return Status::error(EVQL_EARG, err);
+      if (!strings_only_bare(e)) return unsup("string expressions are not lowered yet");
+      if (kp.key_mode == KEY_EXACT && expr_equal(e, kp.group[0])) {
+        q->select_passthrough[i] = true;  // value == the group key itself
+      } else if (!has_input(e)) {
+        // constant expression: no row needed
+      } else {
+        kp.need_first_row = true;
+      }
+    }
+  }
+  if (int(kp.states.size()) > kMaxStateWords) return unsup("too many aggregate state words");
+
+  kp.has_row_filter = plan->row_filter_bits != nullptr;
+
+  // ---- launch shape -------------------------------------------------------------------
+  kp.block = 256;
+  kp.unroll = 4;
+  kp.lds_slots = 0;
+  if (kp.key_mode != KEY_NONE) {
+    const int W = kp.words_per_slot();
+    const uint64_t max_slots_64k = (64 * 1024) / (8 * uint64_t(W)) - 2;
+    uint64_t want = plan->groups_hint ? plan->groups_hint * 2 : 2048;
+    uint64_t s = 256;
+    while (s < want) s <<= 1;
+    if (plan->groups_hint == 0) {
+      while (s > max_slots_64k && s > 256) s >>= 1;
+      kp.lds_slots = int(s);
+    } else if (s <= max_slots_64k) {
+      kp.lds_slots = int(s);
+    } else if (s * 8 * uint64_t(W) + 16 * W <= 150 * 1024) {
+      kp.lds_slots = int(s);  // one workgroup per CU
+      kp.block = 1024;
+    } else {
+      kp.lds_slots = 0;  // high cardinality: aggregate straight into HBM
+    }
+  }
+  return Status();
+}
+
+}  // namespace evql

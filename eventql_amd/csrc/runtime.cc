@@ -1,0 +1,813 @@
+// runtime.cc -- HIP device context, table residency in HBM, JIT of the fused
+// kernel, execution and result emission.
+#include "runtime.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
+#include "sha1.h"
+
+namespace evql {
+
+static thread_local std::string g_last_error;
+static std::string g_cache_dir;
+
+void set_last_error(const std::string& m) { g_last_error = m; }
+const std::string& last_error() { return g_last_error; }
+int fail(int code, const std::string& m) {
+  g_last_error = m;
+  return code;
+}
+void set_cache_dir(const std::string& d) { g_cache_dir = d; }
+
+#define HIP_TRY(expr)                                                             \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      return Status::error(EVQL_EDEVICE, std::string(#expr) + ": " +              \
+                                             hipGetErrorString(e__));             \
+    }                                                                             \
+  } while (0)
+
+static std::string hex_digest(const std::string& s) {
+  Sha1Digest d = sha1(s.data(), s.size());
+  char b[41];
+  for (int i = 0; i < 20; ++i) snprintf(b + 2 * i, 3, "%02x", d.bytes[i]);
+  return std::string(b, 40);
+}
+
+// ---------------------------------------------------------------------------
+// kernel compilation (hiprtc, gfx950) with an in-memory and an on-disk cache
+// ---------------------------------------------------------------------------
+static const char* kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics",
+                                        "-ffp-contract=off", "-std=c++17"};
+
+Status compile_to_code_object(const std::string& source, std::vector<char>* code) {
+  const std::string full = std::string(device_library_source()) + "\n" + source;
+  std::string key = hex_digest(full);
+  std::string cache_file;
+  if (!g_cache_dir.empty()) {
+    cache_file = g_cache_dir + "/" + key + ".hsaco";
+    std::ifstream f(cache_file, std::ios::binary);
+    if (f) {
+      code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      if (!code->empty()) return Status();
+    }
+  }
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, full.c_str(), "evql_fused.hip", 0, nullptr, nullptr) !=
+      HIPRTC_SUCCESS) {
+    return Status::error(EVQL_EDEVICE, "hiprtcCreateProgram failed");
+  }
+  hiprtcResult rc = hiprtcCompileProgram(
+      prog, int(sizeof(kCompileOptions) / sizeof(kCompileOptions[0])), kCompileOptions);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    return Status::error(EVQL_EDEVICE, "kernel compilation failed: " + log);
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code->resize(cs);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  if (!cache_file.empty()) {
+    mkdir(g_cache_dir.c_str(), 0755);
+    std::string tmp = cache_file + ".tmp";
+    std::ofstream f(tmp, std::ios::binary);
+    f.write(code->data(), std::streamsize(code->size()));
+    f.close();
+    rename(tmp.c_str(), cache_file.c_str());
+  }
+  return Status();
+}
+
+Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out, bool load_module) {
+  const std::string key = hex_digest(source);
+  if (ctx) {
+    auto it = ctx->modules.find(key);
+    if (it != ctx->modules.end()) {
+      *out = it->second;
+      return Status();
+    }
+  }
+  std::vector<char> code;
+  Status st = compile_to_code_object(source, &code);
+  if (!st.ok()) return st;
+  out->code_size = code.size();
+  if (load_module) {
+    HIP_TRY(hipModuleLoadData(&out->mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&out->fn, out->mod, "evql_scan_agg"));
+    if (ctx) ctx->modules[key] = *out;
+  }
+  return Status();
+}
+
+// ---------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------
+static uint64_t stream_payload_bytes(const std::vector<uint8_t>& img, const ColumnLayout& c,
+                                     uint64_t nrows) {
+  // encoded bytes actually holding values
+  uint64_t total = 0;
+  auto bitpacked = [&](const std::vector<PageRef>& pages) -> uint64_t {
+    if (pages.empty()) return 0;
+    uint32_t maxv;
+    memcpy(&maxv, &img[pages[0].offset], 4);
+    return 4 + 16ull * bitpack_width(maxv) * ((nrows + 127) / 128);
+  };
+  auto bytes_used = [&](const std::vector<PageRef>& pages) -> uint64_t {
+    if (pages.empty()) return 0;
+    uint64_t full = 0;
+    for (size_t i = 0; i + 1 < pages.size(); ++i) full += pages[i].size;
+    const PageRef& last = pages.back();
+    uint64_t used = last.size;
+    while (used > 0 && img[last.offset + used - 1] == 0) --used;
+    return full + used;
+  };
+  switch (c.storage_type) {
+    case ColumnEncoding::UINT64_PLAIN:
+    case ColumnEncoding::FLOAT_IEEE754:
+      total += c.dlevel_max == 0 ? 8 * nrows : bytes_used(c.data_pages);
+      break;
+    case ColumnEncoding::UINT32_PLAIN:
+      total += c.dlevel_max == 0 ? 4 * nrows : bytes_used(c.data_pages);
+      break;
+    case ColumnEncoding::UINT32_BITPACKED:
+    case ColumnEncoding::BOOLEAN_BITPACKED:
+      total += c.dlevel_max == 0 ? bitpacked(c.data_pages) : bytes_used(c.data_pages);
+      break;
+    default:
+      total += bytes_used(c.data_pages);
+  }
+  if (c.dlevel_max > 0) total += bitpacked(c.dlevel_pages);
+  if (c.rlevel_max > 0) total += bitpacked(c.rlevel_pages);
+  return total;
+}
+
+static Status upload_page_tables(evql_table* t) {
+  t->d_pages.assign(t->layout.columns.size(), std::vector<uint64_t*>(3, nullptr));
+  for (size_t i = 0; i < t->layout.columns.size(); ++i) {
+    const ColumnLayout& c = t->layout.columns[i];
+    const std::vector<PageRef>* lists[3] = {&c.data_pages, &c.rlevel_pages, &c.dlevel_pages};
+    for (int k = 0; k < 3; ++k) {
+      std::vector<uint64_t> offs;
+      for (const auto& p : *lists[k]) offs.push_back(p.offset);
+      if (offs.empty()) offs.push_back(0);
+      // one extra entry so that a tile index one past the end stays in bounds
+      offs.push_back(offs.back());
+      uint64_t* d = nullptr;
+      HIP_TRY(hipMalloc(&d, offs.size() * 8));
+      HIP_TRY(hipMemcpyAsync(d, offs.data(), offs.size() * 8, hipMemcpyHostToDevice,
+                             t->ctx->stream));
+      HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+      t->d_pages[i][k] = d;
+    }
+  }
+  return Status();
+}
+
+Status table_from_image(evql_ctx* ctx, const void* image, size_t len, bool keep_host,
+                        evql_table** out) {
+  std::unique_ptr<evql_table> t(new evql_table());
+  t->ctx = ctx;
+  std::string err = parse_cstable(static_cast<const uint8_t*>(image), len, &t->layout);
+  if (!err.empty()) return Status::error(EVQL_EIO, err);
+  t->image_len = len;
+  const uint8_t* img = static_cast<const uint8_t*>(image);
+  std::vector<uint8_t> tmp(img, img + len);
+  for (const auto& c : t->layout.columns) {
+    t->payload_bytes.push_back(stream_payload_bytes(tmp, c, t->layout.num_rows));
+  }
+  // 1 MiB of zero slack behind the image keeps speculative vector loads legal
+  const size_t slack = 1 << 20;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_image), len + slack));
+  HIP_TRY(hipMemsetAsync(t->d_image + len, 0, slack, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(t->d_image, image, len, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (keep_host) t->host_image.swap(tmp);
+  Status st = upload_page_tables(t.get());
+  if (!st.ok()) return st;
+  *out = t.release();
+  return Status();
+}
+
+}  // namespace evql
+
+evql_table::~evql_table() {
+  if (d_image) hipFree(d_image);
+  for (auto& v : d_pages) {
+    for (auto* p : v) {
+      if (p) hipFree(p);
+    }
+  }
+  for (auto& kv : materialized) {
+    if (kv.second.d_values) hipFree(kv.second.d_values);
+    if (kv.second.d_tags) hipFree(kv.second.d_tags);
+  }
+}
+
+evql_query::~evql_query() {
+  if (d_gtab) hipFree(d_gtab);
+  if (d_status) hipFree(d_status);
+  if (d_counters) hipFree(d_counters);
+  if (d_row_filter) hipFree(d_row_filter);
+  if (ev0) hipEventDestroy(ev0);
+  if (ev1) hipEventDestroy(ev1);
+}
+
+namespace evql {
+
+// ---------------------------------------------------------------------------
+// decode-to-SoA ("materialise") of columns the fused kernel cannot read in place
+// ---------------------------------------------------------------------------
+static uint64_t padded_rows(uint64_t n) {
+  const uint64_t pad = 8192;  // largest tile
+  return (n + pad - 1) / pad * pad + pad;
+}
+
+// host-side sequential walk of a STRING_PLAIN column (length prefixes make the
+// stream inherently sequential, page_reader_lenencstring.cc:37-62): positions,
+// lengths and null tags of every row
+static Status scan_string_column(const evql_table* t, const ColumnLayout& c,
+                                 MaterializedColumn* m) {
+  if (t->host_image.empty()) {
+    return Status::error(EVQL_ENOTSUP, "string column without a host image");
+  }
+  const uint8_t* img = t->host_image.data();
+  const uint64_t n = t->layout.num_rows;
+  m->str_off.resize(n);
+  m->str_len.resize(n);
+  m->str_tag.resize(n);
+  // definition levels
+  std::vector<uint8_t> defined(n, 1);
+  if (c.dlevel_max > 0) {
+    uint32_t maxv = 0;
+    if (!c.dlevel_pages.empty()) memcpy(&maxv, img + c.dlevel_pages[0].offset, 4);
+    const uint32_t b = bitpack_width(maxv);
+    uint32_t buf[128];
+    uint64_t row = 0;
+    for (size_t pi = 0; pi < c.dlevel_pages.size() && row < n; ++pi) {
+      const PageRef& p = c.dlevel_pages[pi];
+      uint64_t pos = pi == 0 ? 4 : 0;
+      for (; pos + 16 * b <= p.size && row < n; pos += 16 * b) {
+        simd_unpack128(img + p.offset + pos, b, buf);
+        for (int k = 0; k < 128 && row < n; ++k, ++row) defined[row] = buf[k] == c.dlevel_max;
+      }
+    }
+    if (b == 0) std::fill(defined.begin(), defined.end(), uint8_t(c.dlevel_max == 0));
+  }
+  // virtual byte stream over the 512 KiB data pages
+  const uint64_t nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
+  auto byte_at = [&](uint64_t pos) -> uint8_t {
+    return img[c.data_pages[pos >> 19].offset + (pos & 0x7ffff)];
+  };
+  uint64_t pos = 0;
+  for (uint64_t r = 0; r < n; ++r) {
+    if (!defined[r]) {
+      m->str_off[r] = 0;
+      m->str_len[r] = 0;
+      m->str_tag[r] = EVQL_STAG_NULL;
+      continue;
+    }
+    uint64_t len = 0;
+    for (int i = 0; i < 10; ++i) {
+      if (pos >= nbytes) return Status::error(EVQL_EIO, "end of column reached");
+      uint8_t b = byte_at(pos++);
+      len |= uint64_t(b & 0x7f) << (7 * i);
+      if (!(b & 0x80)) break;
+    }
+    if (pos + len > nbytes) return Status::error(EVQL_EIO, "end of column reached");
+    m->str_off[r] = pos;
+    m->str_len[r] = uint32_t(len);
+    m->str_tag[r] = 0;
+    pos += len;
+  }
+  return Status();
+}
+
+static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* bits_out) {
+  evql_ctx* ctx = t->ctx;
+  const ColumnLayout& c = t->layout.columns[ca.layout_index];
+  (void) bits_out;
+  if (t->materialized.count(c.name)) return Status();
+  MaterializedColumn m;
+  const uint64_t n = t->layout.num_rows;
+  const uint64_t np = padded_rows(n);
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_values), np * 8));
+  HIP_TRY(hipMemsetAsync(m.d_values, 0, np * 8, s));
+  const int li = ca.layout_index;
+
+  if (c.logical_type == ColumnType::STRING) {
+    Status st = scan_string_column(t, c, &m);
+    if (!st.ok()) return st;
+    m.string_hash = true;
+    uint64_t* d_off = nullptr;
+    uint32_t* d_len = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_off), std::max<uint64_t>(n, 1) * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_len), std::max<uint64_t>(n, 1) * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_tags), np));
+    HIP_TRY(hipMemsetAsync(m.d_tags, 0, np, s));
+    if (n) {
+      HIP_TRY(hipMemcpyAsync(d_off, m.str_off.data(), n * 8, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(d_len, m.str_len.data(), n * 4, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(m.d_tags, m.str_tag.data(), n, hipMemcpyHostToDevice, s));
+      HIP_TRY(launch_string_hash(t->d_image, t->d_pages[li][0], d_off, d_len, n, m.d_values, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(d_off);
+    hipFree(d_len);
+    t->materialized[c.name] = std::move(m);
+    return Status();
+  }
+
+  // where do defined values come from?
+  RtColumn src{};
+  src.pages = t->d_pages[li][0];
+  uint64_t* d_dense = nullptr;  // LEB128 decoded
+  uint64_t nvalues = n;
+  uint64_t* d_tiles = nullptr;
+  const uint64_t ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+
+  if (c.dlevel_max > 0) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_tags), np));
+    HIP_TRY(hipMemsetAsync(m.d_tags, 1, np, s));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tiles), (ntiles + 1) * 8));
+    uint32_t maxv = 0;
+    if (!c.dlevel_pages.empty()) {
+      HIP_TRY(hipMemcpy(&maxv, t->d_image + c.dlevel_pages[0].offset, 4, hipMemcpyDeviceToHost));
+    }
+    const uint32_t dbits = c.dlevel_pages.empty() ? 0 : bitpack_width(maxv);
+    HIP_TRY(launch_dlevel_tags(t->d_image, t->d_pages[li][2], dbits, c.dlevel_max, n, m.d_tags,
+                               d_tiles, s));
+    uint64_t* d_total = d_tiles + ntiles;
+    HIP_TRY(launch_exclusive_scan(d_tiles, ntiles, d_total, s));
+    HIP_TRY(hipMemcpyAsync(&nvalues, d_total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+
+  switch (c.storage_type) {
+    case ColumnEncoding::UINT64_PLAIN:
+    case ColumnEncoding::FLOAT_IEEE754:
+      src.mode = ColAccess::PLAIN64;
+      break;
+    case ColumnEncoding::UINT32_PLAIN:
+      src.mode = ColAccess::PLAIN32;
+      break;
+    case ColumnEncoding::UINT32_BITPACKED:
+    case ColumnEncoding::BOOLEAN_BITPACKED: {
+      src.mode = ColAccess::BITPACKED;
+      uint32_t maxv = 0;
+      if (!c.data_pages.empty()) {
+        HIP_TRY(hipMemcpy(&maxv, t->d_image + c.data_pages[0].offset, 4, hipMemcpyDeviceToHost));
+      }
+      src.bits = c.data_pages.empty() ? 0 : bitpack_width(maxv);
+      break;
+    }
+    case ColumnEncoding::UINT64_LEB128: {
+      const uint64_t nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
+      const uint64_t nchunks = (nbytes + kLebChunk - 1) / kLebChunk;
+      uint64_t* d_chunks = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_chunks), (nchunks + 1) * 8));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), std::max<uint64_t>(nvalues, 1) * 8));
+      if (nchunks) {
+        HIP_TRY(launch_leb128_count(t->d_image, t->d_pages[li][0], nbytes, d_chunks, s));
+        HIP_TRY(launch_exclusive_scan(d_chunks, nchunks, nullptr, s));
+        HIP_TRY(launch_leb128_decode(t->d_image, t->d_pages[li][0], nbytes, d_chunks, nvalues,
+                                     d_dense, s));
+      }
+      HIP_TRY(hipStreamSynchronize(s));
+      hipFree(d_chunks);
+      src.mode = ColAccess::SOA;
+      src.soa = d_dense;
+      break;
+    }
+    default:
+      return Status::error(EVQL_ENOTSUP, "unsupported column encoding");
+  }
+
+  if (c.dlevel_max > 0) {
+    HIP_TRY(launch_expand_nullable(t->d_image, src, m.d_tags, d_tiles, n, m.d_values, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(d_tiles);
+    if (d_dense) hipFree(d_dense);
+  } else {
+    // non-nullable LEB128: the dense decode already is the SoA column
+    if (d_dense) {
+      HIP_TRY(hipMemcpyAsync(m.d_values, d_dense, n * 8, hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      hipFree(d_dense);
+    }
+  }
+  t->materialized[c.name] = std::move(m);
+  return Status();
+}
+
+// ---------------------------------------------------------------------------
+// query execution
+// ---------------------------------------------------------------------------
+static uint64_t word_identity(int op) {
+  switch (op) {
+    case 2: return 0xFFFFFFFFFFFFFFFFull;
+    case 3: return 0ull;
+    case 4: return 0x7FFFFFFFFFFFFFFFull;
+    case 5: return 0x8000000000000000ull;
+    case 6: return 0x7FF0000000000000ull;
+    case 7: return 0xFFF0000000000000ull;
+    default: return 0ull;
+  }
+}
+
+Status query_prepare(evql_query* q) {
+  evql_table* t = q->table;
+  evql_ctx* ctx = q->ctx;
+  // resolve bit widths and materialise SoA columns
+  for (auto& c : q->kp.cols) {
+    const ColumnLayout& cl = t->layout.columns[c.layout_index];
+    if (c.mode == ColAccess::BITPACKED) {
+      uint32_t maxv = 0;
+      if (!cl.data_pages.empty()) {
+        HIP_TRY(hipMemcpy(&maxv, t->d_image + cl.data_pages[0].offset, 4, hipMemcpyDeviceToHost));
+      }
+      c.bits = cl.data_pages.empty() ? 0 : bitpack_width(maxv);
+    } else if (c.mode == ColAccess::SOA) {
+      Status st = materialize_column(t, c, nullptr);
+      if (!st.ok()) return st;
+    }
+  }
+  q->source = generate_kernel_source(q->kp);
+  Status st = compile_kernel(ctx, q->source, &q->module, true);
+  if (!st.ok()) return st;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_status), 16));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_counters), 64));
+  HIP_TRY(hipEventCreate(&q->ev0));
+  HIP_TRY(hipEventCreate(&q->ev1));
+  if (!q->row_filter_host.empty()) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_row_filter), q->row_filter_host.size() + 16));
+    HIP_TRY(hipMemcpy(q->d_row_filter, q->row_filter_host.data(), q->row_filter_host.size(),
+                      hipMemcpyHostToDevice));
+  }
+  // persistent grid: one wave of workgroups per CU slot
+  int per_cu = 1;
+  hipError_t oe = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, q->module.fn,
+                                                                     q->kp.block, 0);
+  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  q->grid = ctx->num_cus * per_cu;
+  return Status();
+}
+
+static Status alloc_gtab(evql_query* q, uint64_t gcap) {
+  if (q->d_gtab) {
+    hipFree(q->d_gtab);
+    q->d_gtab = nullptr;
+  }
+  q->gcap = gcap;
+  const uint64_t stride = gcap + 8;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_gtab),
+                    stride * uint64_t(q->kp.words_per_slot()) * 8));
+  return Status();
+}
+
+Status query_launch(evql_query* q) {
+  evql_ctx* ctx = q->ctx;
+  evql_table* t = q->table;
+  const KernelPlan& kp = q->kp;
+  hipStream_t s = ctx->stream;
+  if (!q->d_gtab) {
+    uint64_t want = kp.key_mode == KEY_NONE ? 8 : std::max<uint64_t>(q->groups_hint * 4, 1 << 16);
+    uint64_t cap = 8;
+    while (cap < want) cap <<= 1;
+    Status st = alloc_gtab(q, cap);
+    if (!st.ok()) return st;
+  }
+  const uint64_t stride = q->gcap + 8;
+  TableInitArgs ia{};
+  ia.words = q->d_gtab;
+  ia.stride = stride;
+  ia.nwords = uint32_t(kp.words_per_slot());
+  ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
+  int w = 1;
+  if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
+  HIP_TRY(launch_table_init(ia, s));
+  HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
+  HIP_TRY(hipMemsetAsync(q->d_counters, 0, 64, s));
+
+  HostArgs a{};
+  a.image = t->d_image;
+  const uint64_t nrows = t->layout.num_rows;
+  a.row_begin = std::min(q->row_begin, nrows);
+  a.row_end = q->row_end ? std::min(q->row_end, nrows) : nrows;
+  const uint64_t T = uint64_t(kp.tile_rows());
+  a.tile0 = a.row_begin / T;
+  a.ntiles = a.row_end > a.row_begin ? (a.row_end + T - 1) / T - a.tile0 : 0;
+  a.row_filter = q->d_row_filter;
+  a.row_filter_len = q->row_filter_len;
+  a.gtab = q->d_gtab;
+  a.gcap = q->gcap;
+  a.status = q->d_status;
+  a.counters = q->d_counters;
+  for (size_t i = 0; i < kp.cols.size(); ++i) {
+    const ColAccess& c = kp.cols[i];
+    a.col[i].pages = t->d_pages[c.layout_index][0];
+    a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
+    if (c.mode == ColAccess::SOA) {
+      const MaterializedColumn& m = t->materialized[c.name];
+      a.col[i].soa = m.d_values;
+      a.col[i].tags = m.d_tags;
+    }
+  }
+  size_t sz = sizeof(HostArgs);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                    HIP_LAUNCH_PARAM_END};
+  HIP_TRY(hipEventRecord(q->ev0, s));
+  if (a.ntiles > 0) {
+    int grid = q->grid;
+    if (uint64_t(grid) > a.ntiles) grid = int(a.ntiles);
+    HIP_TRY(hipModuleLaunchKernel(q->module.fn, grid, 1, 1, kp.block, 1, 1, 0, s, nullptr, config));
+  }
+  HIP_TRY(hipEventRecord(q->ev1, s));
+  q->launched = true;
+  q->stats.n_kernel_launches = 2;
+  q->stats.rows_scanned = a.row_end - a.row_begin;
+  return Status();
+}
+
+static Status fetch_results(evql_query* q);
+
+Status query_finish(evql_query* q) {
+  if (!q->launched) return Status::error(EVQL_EARG, "query was not launched");
+  evql_ctx* ctx = q->ctx;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    uint32_t status[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(status, q->d_status, 16, hipMemcpyDeviceToHost));
+    if (status[0] & 1u) return Status::error(EVQL_ERUNTIME, "division by zero");
+    if (status[0] & 4u) return Status::error(EVQL_ERUNTIME, "modulo by zero");
+    if (status[0] & 2u) {
+      // group table too small: grow and run again
+      Status st = alloc_gtab(q, q->gcap * 4);
+      if (!st.ok()) return st;
+      st = query_launch(q);
+      if (!st.ok()) return st;
+      continue;
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, q->ev0, q->ev1);
+    q->stats.kernel_ms = ms;
+    q->stats.total_ms = ms;
+    uint64_t counters[8];
+    HIP_TRY(hipMemcpy(counters, q->d_counters, 64, hipMemcpyDeviceToHost));
+    q->stats.rows_passed = counters[0];
+    q->stats.used_lds_table = q->kp.lds_slots > 0;
+    q->launched = false;
+    return fetch_results(q);
+  }
+  return Status::error(EVQL_ENOMEM, "group table kept overflowing");
+}
+
+static Status fetch_results(evql_query* q) {
+  evql_ctx* ctx = q->ctx;
+  evql_table* t = q->table;
+  const KernelPlan& kp = q->kp;
+  hipStream_t s = ctx->stream;
+  const uint32_t nwords = uint32_t(kp.words_per_slot());
+  const uint64_t stride = q->gcap + 8;
+  const uint64_t maxrec = q->gcap + 2;
+  uint64_t* d_rec = nullptr;
+  uint64_t* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), 8));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+  // first pass only counts (max_records = 0) so that the record buffer is sized
+  // by the number of groups, not by the table capacity
+  HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, nullptr, 0, d_cnt, s));
+  uint64_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n > maxrec) n = maxrec;
+  q->ngroups = n;
+  q->records.assign(n * (nwords + 1), 0);
+  if (n) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec), n * (nwords + 1) * 8));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+    HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec, n, d_cnt, s));
+    HIP_TRY(hipMemcpyAsync(q->records.data(), d_rec, n * (nwords + 1) * 8,
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  // deterministic output order: by first row (scan order) or by identity
+  {
+    const size_t rw = nwords + 1;
+    std::vector<uint64_t> idx(n);
+    for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+    const size_t keyw = kp.need_first_row ? 2 : 1;
+    const uint64_t* r = q->records.data();
+    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
+      const uint64_t ka = r[a * rw + keyw], kb = r[b * rw + keyw];
+      if (ka != kb) return ka < kb;
+      return r[a * rw] < r[b * rw];
+    });
+    std::vector<uint64_t> sorted(q->records.size());
+    for (uint64_t i = 0; i < n; ++i) {
+      memcpy(&sorted[i * rw], &r[idx[i] * rw], rw * 8);
+    }
+    q->records.swap(sorted);
+  }
+  // first-row values of every scan column
+  q->first_vals.clear();
+  q->first_tags.clear();
+  if (kp.need_first_row && n) {
+    const uint32_t nc = uint32_t(kp.cols.size());
+    std::vector<uint64_t> rows(n);
+    const size_t rw = nwords + 1;
+    for (uint64_t i = 0; i < n; ++i) rows[i] = q->records[i * rw + 2];
+    std::vector<RtColumn> rc(nc);
+    for (uint32_t c = 0; c < nc; ++c) {
+      const ColAccess& ca = kp.cols[c];
+      rc[c].pages = t->d_pages[ca.layout_index][0];
+      rc[c].mode = ca.mode;
+      rc[c].bits = ca.bits;
+      if (ca.mode == ColAccess::SOA) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].soa = m.d_values;
+        rc[c].tags = m.d_tags;
+      }
+    }
+    uint64_t* d_rows = nullptr;
+    RtColumn* d_cols = nullptr;
+    uint64_t* d_vals = nullptr;
+    uint8_t* d_tags = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), n * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cols), nc * sizeof(RtColumn)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vals), n * nc * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tags), n * nc));
+    HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_cols, rc.data(), nc * sizeof(RtColumn), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_gather_rows(t->d_image, d_cols, nc, d_rows, n, d_vals, d_tags, s));
+    q->first_vals.resize(n * nc);
+    q->first_tags.resize(n * nc);
+    HIP_TRY(hipMemcpyAsync(q->first_vals.data(), d_vals, n * nc * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(q->first_tags.data(), d_tags, n * nc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(d_rows);
+    hipFree(d_cols);
+    hipFree(d_vals);
+    hipFree(d_tags);
+  }
+  if (d_rec) hipFree(d_rec);
+  hipFree(d_cnt);
+  q->stats.num_groups = n;
+  q->emit_pos = 0;
+  q->executed = true;
+  return Status();
+}
+
+// ---------------------------------------------------------------------------
+// result emission: GroupByExpression::nextBatch (groupby.cc:187-220)
+// ---------------------------------------------------------------------------
+static Value agg_value(const evql_query* q, const AggPlan& a, const uint64_t* st) {
+  Value v;
+  v.tag = 0;
+  const uint64_t w0 = st[a.first_word];
+  switch (a.fn) {
+    case EVQL_AGG_COUNT:
+    case EVQL_AGG_SUM_UINT64:
+      v.type = EVQL_T_UINT64;
+      v.bits = w0;
+      break;
+    case EVQL_AGG_SUM_INT64:
+      v.type = EVQL_T_INT64;
+      v.bits = w0;
+      break;
+    case EVQL_AGG_SUM_FLOAT64:
+      v.type = EVQL_T_FLOAT64;
+      v.bits = w0;
+      break;
+    case EVQL_AGG_MIN_UINT64:
+    case EVQL_AGG_MAX_UINT64:
+    case EVQL_AGG_MIN_INT64:
+    case EVQL_AGG_MAX_INT64:
+    case EVQL_AGG_MIN_FLOAT64:
+    case EVQL_AGG_MAX_FLOAT64: {
+      v.type = (a.fn <= EVQL_AGG_MAX_UINT64) ? EVQL_T_UINT64
+               : (a.fn <= EVQL_AGG_MAX_INT64 ? EVQL_T_INT64 : EVQL_T_FLOAT64);
+      const uint64_t cnt = st[a.first_word + 1];
+      if (cnt == 0) {
+        v.bits = 0;
+        v.tag = EVQL_STAG_NULL;
+      } else {
+        v.bits = w0;
+      }
+      break;
+    }
+    default: {  // mean
+      v.type = EVQL_T_FLOAT64;
+      const uint64_t cnt = st[a.first_word + 1];
+      if (cnt == 0) {
+        v.bits = 0;
+        v.tag = EVQL_STAG_NULL;
+      } else {
+        double sum, m;
+        memcpy(&sum, &w0, 8);
+        m = sum / double(cnt);
+        memcpy(&v.bits, &m, 8);
+      }
+    }
+  }
+  (void) q;
+  return v;
+}
+
+Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows) {
+  if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
+  const KernelPlan& kp = q->kp;
+  evql_table* t = q->table;
+  const size_t nsel = q->select.size();
+  q->out_cols.assign(nsel, std::vector<uint8_t>());
+  const size_t rw = size_t(kp.words_per_slot()) + 1;
+  const uint32_t nc = uint32_t(kp.cols.size());
+  size_t emitted = 0;
+  std::vector<Value> scan_vals(nc), sel_inputs(q->scan_select.size());
+  while (q->emit_pos < q->ngroups && emitted < max_rows) {
+    const uint64_t g = q->emit_pos;
+    const uint64_t* rec = &q->records[g * rw];
+    const uint64_t kind = rec[0], ident = rec[1];
+    const uint64_t* st = rec + 1 + kp.state_word_base();
+    bool have_inputs = false;
+    if (kp.need_first_row) {
+      const uint64_t row = rec[2];
+      for (uint32_t c = 0; c < nc; ++c) {
+        const ColAccess& ca = kp.cols[c];
+        Value v;
+        v.type = ca.stype;
+        v.tag = q->first_tags[uint64_t(c) * q->ngroups + g];
+        const uint64_t raw = q->first_vals[uint64_t(c) * q->ngroups + g];
+        if (ca.string_hash) {
+          const MaterializedColumn& m = t->materialized[ca.name];
+          v.tag = m.str_tag[row];
+          if (!v.tag) {
+            const ColumnLayout& cl = t->layout.columns[ca.layout_index];
+            v.str.resize(m.str_len[row]);
+            for (uint32_t k = 0; k < m.str_len[row]; ++k) {
+              const uint64_t pos = m.str_off[row] + k;
+              v.str[k] = char(t->host_image[cl.data_pages[pos >> 19].offset + (pos & 0x7ffff)]);
+            }
+          }
+        } else if (ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float) {
+          double d = double(raw);
+          memcpy(&v.bits, &d, 8);
+        } else if (ca.stype == EVQL_T_BOOL) {
+          v.bits = raw != 0;
+        } else {
+          v.bits = raw;
+        }
+        scan_vals[c] = v;
+      }
+      for (size_t j = 0; j < q->scan_select.size(); ++j) {
+        std::string e = eval_expr(q->scan_select[j].call, scan_vals, nullptr, &sel_inputs[j]);
+        if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+      }
+      have_inputs = true;
+    }
+    for (size_t i = 0; i < nsel; ++i) {
+      const LoweredProgram& lp = q->select[i];
+      Value out;
+      if (lp.is_aggregate) {
+        Value av = agg_value(q, kp.aggs[q->select_agg_index[i]], st);
+        std::string e = eval_expr(lp.call, have_inputs ? sel_inputs : std::vector<Value>(), &av, &out);
+        if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+      } else if (q->select_passthrough[i]) {
+        out.type = lp.return_type;
+        if (kind == 2) {
+          out.bits = 0;
+          out.tag = EVQL_STAG_NULL;
+        } else {
+          out.bits = ident;
+          out.tag = 0;
+        }
+      } else {
+        std::string e = eval_expr(lp.call, have_inputs ? sel_inputs : std::vector<Value>(), nullptr, &out);
+        if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+      }
+      append_svector(lp.return_type, out, &q->out_cols[i]);
+    }
+    ++q->emit_pos;
+    ++emitted;
+  }
+  for (size_t i = 0; i < nsel; ++i) {
+    cols[i].data = q->out_cols[i].data();
+    cols[i].size = q->out_cols[i].size();
+  }
+  *nrows = emitted;
+  return Status();
+}
+
+}  // namespace evql

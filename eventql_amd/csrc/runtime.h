@@ -1,0 +1,140 @@
+// runtime.h -- device context, HBM-resident tables and query objects behind the
+// C ABI (include/evql_gpu.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "aot_kernels.h"
+#include "codegen.h"
+#include "cstable_format.h"
+#include "plan_ir.h"
+
+namespace evql {
+
+// host mirror of the device-side EvqlArgs / EvqlColArg (evql_device.h)
+struct HostColArg {
+  const uint64_t* pages;
+  const uint64_t* soa;
+  const uint8_t* tags;
+  uint64_t npages;
+};
+static const uint32_t EVQL_MAX_COLS_HOST = 16;
+struct HostArgs {
+  const uint8_t* image;
+  uint64_t row_begin, row_end, ntiles, tile0;
+  const uint8_t* row_filter;
+  uint64_t row_filter_len;
+  uint64_t* gtab;
+  uint64_t gcap;
+  uint32_t* status;
+  uint64_t* counters;
+  HostColArg col[16];
+};
+
+struct Status {
+  int code = EVQL_OK;
+  std::string msg;
+  bool ok() const { return code == EVQL_OK; }
+  static Status error(int c, const std::string& m) {
+    Status s;
+    s.code = c;
+    s.msg = m;
+    return s;
+  }
+};
+
+struct Module {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  size_t code_size = 0;
+};
+
+}  // namespace evql
+
+struct evql_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 256;
+  std::map<std::string, evql::Module> modules;  // by source fingerprint
+};
+
+// a decoded-to-SoA column cached on the table
+struct MaterializedColumn {
+  uint64_t* d_values = nullptr;
+  uint8_t* d_tags = nullptr;
+  bool string_hash = false;
+  // strings: host-side positions for result emission
+  std::vector<uint64_t> str_off;
+  std::vector<uint32_t> str_len;
+  std::vector<uint8_t> str_tag;
+};
+
+struct evql_table {
+  evql_ctx* ctx = nullptr;
+  evql::TableLayout layout;
+  uint8_t* d_image = nullptr;
+  uint64_t image_len = 0;
+  std::vector<uint8_t> host_image;  // kept for string emission; empty if generated
+  // device page tables: [column][0 data, 1 rlevel, 2 dlevel]
+  std::vector<std::vector<uint64_t*>> d_pages;
+  std::vector<uint64_t> payload_bytes;
+  std::map<std::string, MaterializedColumn> materialized;
+  ~evql_table();
+};
+
+struct evql_query {
+  evql_ctx* ctx = nullptr;
+  evql_table* table = nullptr;
+  // plan
+  std::vector<evql::LoweredProgram> scan_select, group, select;
+  evql::LoweredProgram where;
+  bool has_where = false;
+  evql::KernelPlan kp;
+  std::vector<int> select_agg_index;  // select expr -> index into kp.aggs or -1
+  std::vector<bool> select_passthrough;
+  uint32_t group_mode = EVQL_MODE_FINAL;
+  uint64_t groups_hint = 0;
+  uint64_t row_begin = 0, row_end = 0;
+  std::vector<uint8_t> row_filter_host;
+  uint64_t row_filter_len = 0;
+  uint8_t* d_row_filter = nullptr;
+  std::string source;
+  evql::Module module;
+  // execution state
+  uint64_t* d_gtab = nullptr;
+  uint64_t gcap = 0;
+  uint32_t* d_status = nullptr;
+  uint64_t* d_counters = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool launched = false;
+  bool executed = false;
+  int grid = 0;
+  // results
+  std::vector<uint64_t> records;  // dense [kind, ident, (first_row), states...]
+  uint64_t ngroups = 0;
+  std::vector<uint64_t> first_vals;  // [col][group]
+  std::vector<uint8_t> first_tags;
+  uint64_t emit_pos = 0;
+  std::vector<std::vector<uint8_t>> out_cols;
+  evql_query_stats_t stats{};
+  ~evql_query();
+};
+
+struct evql_writer {
+  std::unique_ptr<evql::TableWriter> w;
+  std::vector<evql::ColumnSpec> specs;
+};
+
+namespace evql {
+void set_last_error(const std::string& m);
+int fail(int code, const std::string& m);
+
+Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out,
+                      bool load_module);
+Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan,
+                         evql_query* q, bool* unsupported);
+}  // namespace evql
