@@ -1,9 +1,7 @@
 """ctypes declarations of the C ABI in include/evql_gpu.h.
 
 Only struct layouts and constants live here; loading libevql_mi355x.so is done
-in eventql_amd/__init__.py.  The same struct layouts are used by the test-only
-oracle (tests/oracle_lib.py) because the oracle consumes the same plan
-descriptor.
+in eventql_amd/__init__.py.
 """
 import ctypes as C
 

@@ -1,0 +1,141 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports
+every symbol include/evql_gpu.h declares, refuses to compute without a device,
+lowers/compiles plans for gfx950, and reports non-lowerable plans the way the
+adapter expects (EVQL_ENOTSUP => fall back to the CPU operators)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import eventql_amd as E
+from eventql_amd import capi as K, bench_plans as B
+from eventql_amd.plan import Plan, col, count, sum_, min_, mean, If, CompileError, Agg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "evql_gpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(evql_[a-z0-9_]+)\s*\(", hdr))
+    names = {n for n in names if not n.endswith("_fn")}
+    assert len(names) > 35
+    L = C.CDLL(E.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_device(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(E.EvqlError) as ei:
+        E.Context(0)
+    assert ei.value.code == K.EVQL_EDEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """the oracle is test infrastructure: nothing under eventql_amd/ or include/
+    may import, link or name it"""
+    bad = []
+    for base in ("eventql_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if "_obj" in dp or "_kcache" in dp:
+                continue
+            for fn in fns:
+                if not fn.endswith((".py", ".cc", ".h", ".hip", ".c", "Makefile")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                if re.search(r"oracle_lib|liboracle|orc_query_run|libcstable_ref|oracle/", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def _cols(*names, **over):
+    d = {c["name"]: dict(c) for c in B.PLAIN_COLUMNS}
+    out = []
+    for n in names:
+        c = d[n]
+        c.update(over.get(n, {}))
+        out.append(c)
+    return out
+
+
+def test_compile_benchmark_kernels_for_gfx950(built, tmp_path):
+    for fn in (B.config2, B.config3, B.config4):
+        size = E.compile_only(fn(), B.PLAIN_COLUMNS, cache_dir=str(tmp_path))
+        assert size > 4000
+    assert len(os.listdir(tmp_path)) == 3
+    # second call is served from the on-disk cache
+    assert E.compile_only(B.config3(), B.PLAIN_COLUMNS, cache_dir=str(tmp_path)) > 4000
+
+
+def test_compile_expression_coverage(built, tmp_path):
+    """every lowerable op family (SURVEY 8a op table) generates compilable HIP"""
+    S = dict(B.SCHEMA)
+    a, b, v, k = col("a"), col("b"), col("v"), col("k")
+    plan = Plan(S, select=[k, sum_(If(a > b, a - b, b / (a + 1))), count(v), min_(v),
+                           mean(a), sum_(v) + 1.0],
+                group_by=[k], where=(((a + b) * 2 - 1) % 7 > 3) | ((~(v * 1.5 / 2.0 >= 10.0)) &
+                                                                   a.neq(b)),
+                groups_hint=1000)
+    assert E.compile_only(plan, B.PLAIN_COLUMNS, cache_dir=str(tmp_path)) > 4000
+    # multi-column key (hashed identity), global aggregate, bit-packed + u32 columns
+    plan = Plan(S, select=[k, b, count(1)], group_by=[k, b], groups_hint=100000)
+    assert E.compile_only(plan, B.PLAIN_COLUMNS, cache_dir=str(tmp_path)) > 4000
+    plan = Plan(S, select=[count(1), sum_(a)], where=a < 100)
+    cols = _cols("k", "a", "b", "v", a=dict(storage_type=K.ENC_UINT32_BITPACKED, bits=17),
+                 b=dict(storage_type=K.ENC_UINT32_PLAIN))
+    assert E.compile_only(plan, cols, cache_dir=str(tmp_path)) > 4000
+
+
+def test_not_lowerable_plans_are_reported(built):
+    S = dict(B.SCHEMA)
+    # count_distinct: lowerable set excludes it -> ENOTSUP
+    p = Plan(S, select=[col("k"), count(1)], group_by=[col("k")])
+    p.select[1].struct.aggregate_fn = K.AGG_COUNT_DISTINCT_UINT64
+    p._select[1].aggregate_fn = K.AGG_COUNT_DISTINCT_UINT64
+    with pytest.raises(E.EvqlError) as ei:
+        E.compile_only(p, B.PLAIN_COLUMNS)
+    assert ei.value.code == K.EVQL_ENOTSUP
+    # INT64 scan column: the reference answers EARG "illegal column type: INT64"
+    S2 = dict(S)
+    S2["a"] = K.T_INT64
+    p = Plan(S2, select=[count(1)], where=col("a") > -1)
+    with pytest.raises(E.EvqlError) as ei:
+        E.compile_only(p, B.PLAIN_COLUMNS)
+    assert ei.value.code == K.EVQL_EARG and "INT64" in ei.value.msg
+    # unknown column
+    p = Plan(dict(zz=K.T_UINT64), select=[count(1)], where=col("zz") > 1)
+    with pytest.raises(E.EvqlError) as ei:
+        E.compile_only(p, B.PLAIN_COLUMNS)
+    assert ei.value.code == K.EVQL_EARG
+
+
+def test_plan_builder_matches_reference_compiler_layout():
+    """bytecode layout of compiler.cc:50-248"""
+    S = dict(a=K.T_UINT64, k=K.T_UINT64)
+    p = Plan(S, select=[sum_(If(col("a") > 5, 1, 0)) + 1], group_by=[col("k")])
+    prog = p.select[0]
+    ops = [(i.op, i.arg0) for i in prog.code]
+    # method_call: GET; LITERAL 1; CALL add; RETURN
+    assert ops[0] == (K.X_CALL_INSTANCE, K.INSTANCE_GET)
+    assert ops[1][0] == K.X_LITERAL and ops[2] == (K.X_CALL_PURE, K.FN(K.FAM_ADD, K.TS_UINT64))
+    assert ops[3][0] == K.X_RETURN
+    acc = prog.struct.method_accumulate
+    assert acc == 4
+    # accumulate: a; 5; gt; CJUMP ->T; 0; JUMP ->E; T: 1; ACCUMULATE; RETURN
+    kinds = [o[0] for o in ops[acc:]]
+    assert kinds == [K.X_INPUT, K.X_LITERAL, K.X_CALL_PURE, K.X_CJUMP, K.X_LITERAL, K.X_JUMP,
+                     K.X_LITERAL, K.X_CALL_INSTANCE, K.X_RETURN]
+    cj = ops[acc + 3]
+    assert cj[1] == acc + 6           # true branch starts after the JUMP
+    assert ops[acc + 5][1] == acc + 7  # JUMP -> end of IF
+    # count(x) inserts to_nil; literals type by sign / dot
+    p = Plan(S, select=[count(col("a"))])
+    assert [i.op for i in p.select[0].code][2:5] == [K.X_INPUT, K.X_CALL_PURE, K.X_CALL_INSTANCE]
+    with pytest.raises(CompileError):
+        Plan(S, select=[count(1)], where=col("a") > 1.5)  # gt<uint64,float64> is a type error
+    with pytest.raises(CompileError):
+        Plan(S, select=[Agg("max_by", col("a"))])

@@ -1,0 +1,377 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on identical
+inputs.  Integer / string / NULL results must be bit-exact; float64 sums and
+means within 1e-6 relative (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import eventql_amd as E
+from eventql_amd import capi as K, synth, bench_plans as B
+from eventql_amd.plan import Plan, col, count, sum_, min_, max_, mean, If, lit, Call
+import oracle_lib as O
+import tables as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mixed(ctx):
+    img, c = T.mixed_table(300_000)
+    t = ctx.open_image(img)
+    yield t, img, c
+    t.close()
+
+
+def check(t, img, key_cols=1, **kw):
+    plan = Plan(T.MIXED_SCHEMA, **kw)
+    exp = O.oracle_run(img, plan)
+    q = t.query(plan)
+    try:
+        got = q.run()
+        assert [q.column_type(i) for i in range(q.column_count())] == exp.types
+        assert got.nrows == exp.nrows, (got.nrows, exp.nrows)
+        T.compare_results(got.rows(), exp.rows(), exp.types, key_cols=key_cols)
+        st = q.stats()
+        assert st["rows_passed"] == exp.rows_passed
+        return got, exp, st
+    finally:
+        q.close()
+
+
+W = (col("a") > 30000) & (col("b") < 30000)
+
+
+@pytest.mark.parametrize("key", ["k", "k10", "p", "b", "t", "f"])
+def test_group_by_every_direct_and_decoded_encoding(mixed, key):
+    """keys from LEB128 (decoded to SoA), narrow bit-packed, UINT32_PLAIN,
+    UINT64_PLAIN, DATETIME/LEB128 and BOOLEAN columns"""
+    t, img, _ = mixed
+    check(t, img, select=[col(key), sum_(col("a")), count(1), sum_(col("v")), sum_(col("p"))],
+          group_by=[col(key)], where=W)
+
+
+def test_config_shapes(mixed):
+    t, img, _ = mixed
+    check(t, img, select=[col("k"), sum_(col("v")), count(1)], group_by=[col("k")],
+          groups_hint=1000)
+    check(t, img, select=[col("k"), sum_(col("v")), count(1), sum_(col("b"))],
+          group_by=[col("k")], where=W, groups_hint=1000)
+
+
+@pytest.mark.parametrize("hint", [0, 10, 1000, 5000, 100000])
+def test_group_table_variants(mixed, hint):
+    """LDS table sizes, the one-workgroup-per-CU variant and the HBM-only table"""
+    t, img, _ = mixed
+    _, _, st = check(t, img, select=[col("k"), sum_(col("a")), count(1), min_(col("b")),
+                                     max_(col("v"))],
+                     group_by=[col("k")], where=col("a") > 1000, groups_hint=hint)
+    assert st["num_groups"] == 1000
+
+
+def test_high_cardinality(mixed):
+    t, img, c = mixed
+    # 300k distinct 64-bit keys; LDS table overflows into the HBM table
+    _, _, st = check(t, img, select=[col("w"), count(1), sum_(col("a"))], group_by=[col("w")])
+    assert st["num_groups"] == len(set(c["w"].tolist()))
+    check(t, img, select=[col("w"), count(1), sum_(col("a"))], group_by=[col("w")],
+          groups_hint=400000)
+    check(t, img, select=[col("b"), count(1), sum_(col("v")), max_(col("a"))],
+          group_by=[col("b")], groups_hint=70000)
+
+
+def test_global_aggregates(mixed):
+    t, img, _ = mixed
+    check(t, img, key_cols=0, select=[count(1)])
+    check(t, img, key_cols=0, select=[count(1), sum_(col("a")), sum_(col("v")), min_(col("a")),
+                                      max_(col("v")), mean(col("b")), mean(col("v"))], where=W)
+    # zero passing rows => zero result rows (groupby.cc:183,192)
+    got, _, _ = check(t, img, key_cols=0, select=[count(1), sum_(col("a"))],
+                      where=col("v") > 8000000.5)
+    assert got.nrows == 0
+
+
+def test_nullable_columns(mixed):
+    t, img, _ = mixed
+    # NULL contributes 0 to sum, is counted by count(x), skipped by min/max/mean
+    check(t, img, select=[col("k"), sum_(col("n")), count(col("n")), min_(col("n")),
+                          max_(col("n")), mean(col("n")), sum_(col("nv")), min_(col("nv")),
+                          mean(col("nv")), sum_(col("nb")), max_(col("nb"))],
+          group_by=[col("k")])
+    # NULL compares as 0 in predicates
+    check(t, img, key_cols=0, select=[count(1)], where=col("n") > 5)
+    check(t, img, key_cols=0, select=[count(1)], where=col("nv") < 1.0)
+    # NULL keys form their own group, distinct from 0
+    got, _, _ = check(t, img, select=[col("nb"), count(1), sum_(col("a"))], group_by=[col("nb")])
+    assert None in [r[0] for r in got.rows()] and 0 in [r[0] for r in got.rows()]
+    check(t, img, select=[col("nv"), count(1)], group_by=[col("nv")], groups_hint=20000)
+    # only-NULL input => min/mean are NULL
+    check(t, img, key_cols=0, select=[min_(col("n")), mean(col("n")), count(1)],
+          where=col("n").eq(0))
+
+
+def test_string_keys(mixed):
+    t, img, _ = mixed
+    check(t, img, select=[col("s"), count(1), sum_(col("a"))], group_by=[col("s")])
+    got, _, _ = check(t, img, select=[col("ns"), count(1), sum_(col("v"))],
+                      group_by=[col("ns")])
+    assert None in [r[0] for r in got.rows()]
+    check(t, img, key_cols=2, select=[col("k"), col("s"), count(1)],
+          group_by=[col("k"), col("s")])
+
+
+def test_multi_column_keys_and_first_row(mixed):
+    t, img, _ = mixed
+    check(t, img, key_cols=2, select=[col("k"), col("f"), count(1), sum_(col("a"))],
+          group_by=[col("k"), col("f")])
+    check(t, img, key_cols=2, select=[col("k"), col("nb"), count(1)],
+          group_by=[col("k"), col("nb")], groups_hint=200000)
+    # non-aggregate select expressions: value of the group's FIRST row in scan order
+    check(t, img, select=[col("k"), col("a"), col("v"), col("s"), count(1)],
+          group_by=[col("k")])
+    check(t, img, select=[col("k"), col("a") + col("b"), count(1)], group_by=[col("k")],
+          where=W)
+    # group by an expression
+    check(t, img, select=[col("a") % 10, count(1), sum_(col("b"))], group_by=[col("a") % 10])
+
+
+def test_expressions(mixed):
+    t, img, _ = mixed
+    a, b, v, k, p = col("a"), col("b"), col("v"), col("k"), col("p")
+    check(t, img, select=[k, sum_(If(a > b, a - b, b - a)), sum_(a * b + 7), sum_(v * 1.5 - 2.0),
+                          sum_(v / (v + 1.0)), max_(a / (b + 1)), sum_(p % 13), count(1)],
+          group_by=[k], where=((a + b) % 7 > 2) | ~(v >= 100.0))
+    # uint64 wrap-around and UINT64 -> INT64 conversion with signed compare
+    check(t, img, select=[k, sum_(a - 40000), sum_(b * 281474976710656), count(1)], group_by=[k])
+    check(t, img, select=[k, sum_(Call("to_int64", a) - 40000), min_(Call("to_int64", a) - 40000),
+                          count(1)],
+          group_by=[k], where=(a - lit(-5)) > lit(-1))
+    # post-aggregate arithmetic; the single-instance quirk (sum(a)+sum(b) = 2*sum(a))
+    check(t, img, select=[k, sum_(a) + 1, sum_(a) + sum_(b), sum_(v) * 2.0], group_by=[k])
+    check(t, img, select=[k, sum_(a) + k], group_by=[k])
+    # cmp / eq / neq on floats and bools
+    check(t, img, select=[col("f"), count(1), sum_(If(col("f"), 1, 0))], group_by=[col("f")],
+          where=v.neq(0.0) & Call("cmp", a, b).eq(lit(-1)))
+    # float division by zero is permitted (math.cc:166-170), pow / mod via libm
+    check(t, img, key_cols=0, select=[count(1), max_(Call("pow", v, 0.5)), sum_(Call("mod", v, 3.0))],
+          where=(v / (v - v)) > 1.0)
+
+
+def test_division_by_zero_is_reported(mixed):
+    t, img, _ = mixed
+    plan = Plan(T.MIXED_SCHEMA, select=[count(1)], where=(col("a") / (col("b") - col("b"))) > 1)
+    with pytest.raises(RuntimeError, match="division by zero"):
+        O.oracle_run(img, plan)
+    q = t.query(plan)
+    with pytest.raises(E.EvqlError) as ei:
+        q.run()
+    assert ei.value.code == K.EVQL_ERUNTIME and "division by zero" in ei.value.msg
+    q.close()
+    # ... but only for rows that are actually evaluated (IF guards the division)
+    check(t, img, select=[col("k"), sum_(If(col("b") > 0, col("a") / col("b"), 0))],
+          group_by=[col("k")])
+
+
+def test_row_filter_and_row_range(mixed):
+    t, img, _ = mixed
+    n = 300_000
+    rng = np.random.default_rng(7)
+    keep = rng.random(n) < 0.3
+    check(t, img, select=[col("k"), count(1), sum_(col("a"))], group_by=[col("k")],
+          row_filter=keep.astype(np.uint8), where=col("b") > 1000)
+    # a filter shorter than the table drops the rows beyond it
+    check(t, img, key_cols=0, select=[count(1)], row_filter=np.ones(1000, np.uint8))
+    # prefix scans end on arbitrary rows
+    for end in (1, 2047, 2048, 2049, 65535, 65537, 131073, 299_999):
+        check(t, img, select=[col("k"), count(1), sum_(col("b")), sum_(col("p"))],
+              group_by=[col("k")], row_end=end)
+
+
+def test_row_ranges_partition_the_table(mixed):
+    """partition slices: partial aggregates over [0,m) and [m,n) merged on the
+    device equal the whole-table result (PartialGroupBy -> GroupByMerge)"""
+    import torch
+    t, img, _ = mixed
+    n, m = 300_000, 123_457
+    kw = dict(select=[col("k"), count(1), sum_(col("a")), min_(col("b")), max_(col("v")),
+                      sum_(col("v"))], group_by=[col("k")], where=col("a") > 5000)
+    whole = Plan(T.MIXED_SCHEMA, **kw)
+    exp = O.oracle_run(img, whole)
+    qa = t.query(Plan(T.MIXED_SCHEMA, row_end=m, **kw))
+    qb = t.query(Plan(T.MIXED_SCHEMA, row_begin=m, **kw))
+    qa.execute()
+    qb.execute()
+    rw = qb.record_words()
+    buf = torch.zeros(4096 * rw, dtype=torch.int64, device="cuda")
+    cnt = qb.export_groups(buf.data_ptr(), 4096)
+    assert cnt == 1000
+    qa.import_groups(buf.data_ptr(), cnt)
+    got = qa.fetch_all()
+    T.compare_results(got.rows(), exp.rows(), exp.types)
+    qa.close()
+    qb.close()
+
+
+def _small_table(ctx, cols, specs, n):
+    w = E.Writer(specs)
+    for s in specs:
+        w.put(s["name"], cols[s["name"]], present=cols.get(s["name"] + "_present"))
+    w.commit(n)
+    img = w.image()
+    w.close()
+    return ctx.open_image(img), img
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 65536, 65537, 131073])
+def test_edge_sizes(ctx, n):
+    c = synth.table_columns(max(n, 1))
+    cols = {k: v[:n] for k, v in c.items()}
+    specs = [dict(name="k", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT32_BITPACKED,
+                  bitpack_max_value=1023),
+             dict(name="a", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+             dict(name="v", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754),
+             dict(name="b", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_LEB128)]
+    t, img = _small_table(ctx, cols, specs, n)
+    S = dict(k=K.T_UINT64, a=K.T_UINT64, v=K.T_FLOAT64, b=K.T_UINT64)
+    for kw in (dict(select=[col("k"), count(1), sum_(col("a")), sum_(col("v")), sum_(col("b"))],
+                    group_by=[col("k")]),
+               dict(select=[count(1), sum_(col("b"))], where=col("a") > 30000)):
+        plan = Plan(S, **kw)
+        exp = O.oracle_run(img, plan)
+        got = t.query(plan).run()
+        assert got.nrows == exp.nrows
+        T.compare_results(got.rows(), exp.rows(), exp.types, key_cols=len(kw.get("group_by", [])))
+    t.close()
+
+
+def test_sentinel_and_extreme_keys(ctx):
+    """the key value 2^64-1 is the table's EMPTY marker internally; it must
+    still come out as an ordinary group, next to NULL and 0"""
+    n = 5000
+    i = np.arange(n, dtype=np.uint64)
+    key = np.where(i % 5 == 0, np.uint64(0xFFFFFFFFFFFFFFFF),
+                   np.where(i % 5 == 1, np.uint64(0), i % np.uint64(7)))
+    cols = dict(key=key, key_present=(i % 11 != 3).astype(np.uint8), a=i)
+    specs = [dict(name="key", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN,
+                  dlevel_max=1),
+             dict(name="a", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN)]
+    t, img = _small_table(ctx, cols, specs, n)
+    S = dict(key=K.T_UINT64, a=K.T_UINT64)
+    for hint in (0, 100000):
+        plan = Plan(S, select=[col("key"), count(1), sum_(col("a")), max_(col("a"))],
+                    group_by=[col("key")], groups_hint=hint)
+        exp = O.oracle_run(img, plan)
+        got = t.query(plan).run()
+        T.compare_results(got.rows(), exp.rows(), exp.types)
+        keys = [r[0] for r in got.rows()]
+        assert 0xFFFFFFFFFFFFFFFF in keys and None in keys and 0 in keys
+    t.close()
+
+
+def test_survey_goldens_on_gpu(ctx):
+    """the reference outputs of SURVEY.md 8c(ii), straight from the HIP path"""
+    gold = json.load(open(os.path.join(T.GOLDEN, "survey_8c.json")))
+    img, _ = T.survey_table(1_000_000)
+    t = ctx.open_image(img)
+
+    def run(**kw):
+        return t.query(Plan(T.SURVEY_SCHEMA, **kw)).run()
+
+    assert run(select=[count(1)]).rows() == [(gold["count_1"],)]
+    assert run(select=[count(1)], where=W).rows() == \
+        [(gold["count_where_a_gt_30000_and_b_lt_30000"],)]
+    d = {r[0]: r for r in run(select=[col("k"), sum_(col("a")), count(1), sum_(col("b"))],
+                              group_by=[col("k")], where=W).rows()}
+    g0, g1 = gold["filtered_k0"], gold["filtered_k1"]
+    assert d[0] == (0, g0["sum_a"], g0["count"], g0["sum_b"])
+    assert d[1] == (1, g1["sum_a"], g1["count"], g1["sum_b"])
+    assert run(select=[sum_(col("n")), count(col("n"))], where=col("n") >= 0).rows() == \
+        [tuple(gold["sum_n_count_n_where_n_gte_0"])]
+    assert run(select=[count(1)], where=col("n") > 5).rows() == [(gold["count_where_n_gt_5"],)]
+    assert run(select=[count(1)], where=~((col("a") > 30000) | col("b").eq(5))).rows() == \
+        [(gold["count_where_not_a_gt_30000_or_b_eq_5"],)]
+    d = {r[0]: r[1] for r in run(select=[col("s"), count(1)], group_by=[col("s")]).rows()}
+    for k, v in gold["string_groups"].items():
+        assert d[k.encode()] == v
+    r = run(select=[col("n"), count(1)], group_by=[col("n")], groups_hint=700000)
+    assert r.nrows == gold["high_cardinality_groups_n"]
+    assert {x[0]: x[1] for x in r.rows()}[None] == gold["null_group_count"]
+    assert run(select=[sum_(col("b") * 281474976710656)]).rows() == [(gold["sum_b_times_2_48"],)]
+    t.close()
+
+
+def test_device_generator_matches_host_twin(ctx, tmp_path):
+    n = 700_001
+    t = ctx.generate(n, "kabvu", u_mod=10_000_000)
+    img = t.download_image()
+    path = str(tmp_path / "gen.cst")
+    open(path, "wb").write(img)
+    c = synth.table_columns(n)
+    rd = O.TableReader(path, "orc")
+    for name in "kab":
+        assert (rd.read(name, n, "uint")[3] == c[name]).all()
+    assert (rd.read("v", n, "float")[3] == c["v"]).all()
+    assert (rd.read("u", n, "uint")[3] == c["x"] % np.uint64(10_000_000)).all()
+    rd.close()
+    if O.have_ref():
+        rr = O.TableReader(path, "ref")
+        assert rr.num_rows == n and (rr.read("k", n, "uint")[3] == c["k"]).all()
+        rr.close()
+    t.close()
+    # bit-packed key column at 10 bits, as in config 2 run B
+    t = ctx.generate(300_000, "kv", k_bits=10)
+    img = t.download_image()
+    open(path, "wb").write(img)
+    rd = O.TableReader(path, "orc")
+    assert (rd.read("k", 300_000, "uint")[3] == c["k"][:300_000]).all()
+    rd.close()
+    p = B.config2()
+    exp = O.oracle_run(path, p)
+    got = t.query(p).run()
+    T.compare_results(got.rows(), exp.rows(), exp.types)
+    t.close()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE sizes (1e9 rows, config 3): size-independent properties"""
+    n = 1_000_000_000
+    t = ctx.generate(n, "kabv")
+    q = t.query(B.config3())
+    r1 = q.run()
+    st = q.stats()
+    assert r1.nrows == 1000
+    # checksum of checksums: the per-group counts add up to the passing rows
+    assert sum(r[2] for r in r1.rows()) == st["rows_passed"]
+    assert 0.24 * n < st["rows_passed"] < 0.26 * n
+    # idempotence: integer aggregates identical run to run, float sums within 1e-9
+    r2 = q.run()
+    d1 = {r[0]: r for r in r1.rows()}
+    for r in r2.rows():
+        assert r[2] == d1[r[0]][2] and r[3] == d1[r[0]][3]
+        assert abs(r[1] - d1[r[0]][1]) <= 1e-9 * abs(r[1])
+    q.close()
+    # linearity: two half-table slices add up to the whole
+    qa = t.query(B.config3(row_end=n // 2 + 12345))
+    qb = t.query(B.config3(row_begin=n // 2 + 12345))
+    da = {r[0]: r for r in qa.run().rows()}
+    db = {r[0]: r for r in qb.run().rows()}
+    for k, r in d1.items():
+        assert da[k][2] + db[k][2] == r[2] and da[k][3] + db[k][3] == r[3]
+        assert abs(da[k][1] + db[k][1] - r[1]) <= 1e-9 * abs(r[1])
+    # the 1M-row prefix equals the host-generated table through the oracle
+    qp = t.query(B.config3(row_end=1_000_000))
+    got = qp.run()
+    c = synth.table_columns(1_000_000)
+    m = (c["a"] > 30000) & (c["b"] < 30000)
+    for k, sv, cnt, sb in got.rows():
+        mk = m & (c["k"] == k)
+        assert cnt == int(mk.sum()) and sb == int(c["b"][mk].sum())
+        assert abs(sv - float(c["v"][mk].sum())) <= 1e-6 * abs(sv)
+    for x in (qa, qb, qp):
+        x.close()
+    # count(1) over everything, no predicate
+    q = t.query(Plan(B.SCHEMA, select=[count(1)]))
+    assert q.run().rows() == [(n,)]
+    q.close()
+    t.close()
