@@ -41,6 +41,13 @@ def lib():
         raise ImportError(
             "libevql_mi355x.so is missing: run `make -C eventql_amd/csrc` "
             "(or __graft_entry__.build()); there is no fallback path")
+    # PyTorch bundles its own HIP runtime (same soname, libamdhip64.so.7).  Two HIP
+    # runtimes in one process cannot both own the GPU, so make sure torch's copy
+    # is the one already loaded when our library's NEEDED entries are resolved.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.evql_last_error.restype = C.c_char_p
     L.evql_version.restype = C.c_char_p

@@ -221,7 +221,20 @@ __device__ __forceinline__ void evql_atomic(u64* p, u64 v) {
 // LDS table: returns the slot or -1 when no slot was found within MAXP probes
 template <int MAXP>
 __device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32 h) {
-  u32 s = h & mask;
+  // Probe 0 is the identity slot (low key bits): dense small keys -- dimension
+  // ids, the usual GROUP BY key -- then never collide, and in a wave the probe
+  // loop runs as long as its slowest lane.  Everything else continues along the
+  // mixed-hash linear chain.
+  u32 s = (u32) ident & mask;
+  {
+    u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);
+    if (cur == ident) return (int) s;
+    if (cur == EVQL_EMPTY) {
+      u64 old = atomicCAS(&keys[s], EVQL_EMPTY, ident);
+      if (old == EVQL_EMPTY || old == ident) return (int) s;
+    }
+  }
+  s = h & mask;
 #pragma unroll 1
   for (int probe = 0; probe < MAXP; ++probe) {
     u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);

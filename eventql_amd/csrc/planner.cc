@@ -6,6 +6,7 @@
 //   GroupByExpression(select_exprs, group_exprs, FastCSTableScan(stmt))
 // (sql/scheduler.cc:134-182): scan-level programs index scan columns,
 // group-level programs index the scan's select list.
+#include <cstdlib>
 #include <cstring>
 #include "runtime.h"
 
@@ -290,22 +291,33 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
   kp.unroll = 4;
   kp.lds_slots = 0;
   if (kp.key_mode != KEY_NONE) {
-    const int W = kp.words_per_slot();
-    const uint64_t max_slots_64k = (64 * 1024) / (8 * uint64_t(W)) - 2;
-    uint64_t want = plan->groups_hint ? plan->groups_hint * 2 : 2048;
-    uint64_t s = 256;
-    while (s < want) s <<= 1;
-    if (plan->groups_hint == 0) {
-      while (s > max_slots_64k && s > 256) s >>= 1;
-      kp.lds_slots = int(s);
-    } else if (s <= max_slots_64k) {
-      kp.lds_slots = int(s);
-    } else if (s * 8 * uint64_t(W) + 16 * W <= 150 * 1024) {
-      kp.lds_slots = int(s);  // one workgroup per CU
-      kp.block = 1024;
+    // One 1024-thread workgroup per CU owning (almost) the whole 160 KiB LDS: the
+    // probe loop of a wave runs as long as its slowest lane, so the table is kept
+    // sparse (load factor <= 1/4 where the LDS allows) -- measured on MI355X:
+    // 1000 groups in 4096 slots ran 2.1x faster than in 2048 slots.
+    const uint64_t W = uint64_t(kp.words_per_slot());
+    uint64_t smax = 256;
+    while ((smax * 2 + 2) * 8 * W <= 150 * 1024) smax <<= 1;
+    const uint64_t hint = plan->groups_hint;
+    if (hint != 0 && hint * 2 > smax) {
+      kp.lds_slots = 0;  // high cardinality: aggregate straight into the HBM table
+      kp.block = 256;
     } else {
-      kp.lds_slots = 0;  // high cardinality: aggregate straight into HBM
+      uint64_t s = smax;
+      if (hint != 0) {
+        s = 1024;
+        while (s < hint * 4) s <<= 1;
+        if (s > smax) s = smax;
+      }
+      kp.lds_slots = int(s);
+      kp.block = 1024;
     }
+  }
+  // tuning overrides (experiments only)
+  if (const char* e = getenv("EVQL_FORCE_BLOCK")) kp.block = atoi(e);
+  if (const char* e = getenv("EVQL_FORCE_UNROLL")) kp.unroll = atoi(e);
+  if (const char* e = getenv("EVQL_FORCE_LDS_SLOTS")) {
+    if (kp.key_mode != KEY_NONE) kp.lds_slots = atoi(e);
   }
   return Status();
 }

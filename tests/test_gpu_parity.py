@@ -149,7 +149,8 @@ def test_expressions(mixed):
           group_by=[k], where=(a - lit(-5)) > lit(-1))
     # post-aggregate arithmetic; the single-instance quirk (sum(a)+sum(b) = 2*sum(a))
     check(t, img, select=[k, sum_(a) + 1, sum_(a) + sum_(b), sum_(v) * 2.0], group_by=[k])
-    check(t, img, select=[k, sum_(a) + k], group_by=[k])
+    # (`sum(a) + k` is not a valid reference plan: GroupByExpression::nextBatch runs
+    # method_call with argc = 0, so an X_INPUT there trips vm.cc:135's assert)
     # cmp / eq / neq on floats and bools
     check(t, img, select=[col("f"), count(1), sum_(If(col("f"), 1, 0))], group_by=[col("f")],
           where=v.neq(0.0) & Call("cmp", a, b).eq(lit(-1)))
