@@ -322,6 +322,118 @@ __global__ void __launch_bounds__(kBlock) k_synth(const SynthArgs* ap, u64 nchun
   }
 }
 
+// ---- nested (Dremel) scans ---------------------------------------------------------
+// level stream (bit-packed, width `bits`) -> one byte per slot, plus per-tile
+// counts of slots with level <= thr[c] for up to 4 thresholds (thr = 255 => skip)
+struct LevelCountArgs {
+  const u8* image;
+  const u64* pages;
+  u32 bits;
+  u64 nslots;     // slots to decode (stream capacity)
+  u8* levels;     // out, padded to a tile multiple
+  u64* counts[4];  // out: per tile
+  u32 thr[4];
+};
+
+__global__ void __launch_bounds__(kBlock) k_level_decode(LevelCountArgs a) {
+  const u64 tile = blockIdx.x;
+  const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 cnt[4] = {0, 0, 0, 0};
+  u64 packed = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u64 s = s0 + j;
+    u32 lv = 0xff;
+    if (s < a.nslots) {
+      lv = evql_bitpacked_rt(a.image, a.pages, a.bits, s);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cnt[c] += (lv <= a.thr[c]) ? 1 : 0;
+    }
+    packed |= (u64) (lv & 0xff) << (8 * j);
+  }
+  *reinterpret_cast<u64*>(a.levels + s0) = packed;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (a.counts[c] == nullptr) continue;
+    u32 total;
+    block_excl_scan(cnt[c], &total);
+    if (threadIdx.x == 0) a.counts[c][tile] = total;
+  }
+}
+
+// first slot index at which the inclusive count of (level <= thr) exceeds
+// `target` (i.e. the start of record number `target`), given the scanned tile
+// offsets; writes the stream's slot count when the target is never reached
+__global__ void __launch_bounds__(kBlock) k_find_nth(const u8* levels, const u64* tile_offsets,
+                                                     u64 ntiles, u64 nslots, u32 thr, u64 target,
+                                                     u64* out) {
+  const u64 tile = blockIdx.x;
+  const u64 base = tile_offsets[tile];
+  const u64 next = tile + 1 < ntiles ? tile_offsets[tile + 1] : ~0ull;
+  if (tile == 0 && threadIdx.x == 0 && target == 0) {
+    // degenerate: zero records
+  }
+  if (!(base <= target && target < next)) return;
+  // this tile contains the target-th qualifying slot (0-based): serial scan by
+  // one thread (2048 bytes)
+  if (threadIdx.x != 0) return;
+  u64 seen = base;
+  for (u32 i = 0; i < kDecodeTile; ++i) {
+    const u64 s = tile * kDecodeTile + i;
+    if (s >= nslots) break;
+    if (levels[s] <= thr) {
+      if (seen == target) {
+        *out = s;
+        return;
+      }
+      ++seen;
+    }
+  }
+}
+
+// flat[j] = vals[(inclusive count of leaf slots i <= j with level <= thr) - 1]
+__global__ void __launch_bounds__(kBlock) k_flatten_parent(const u8* leaf_levels,
+                                                           const u64* tile_offsets, u32 thr,
+                                                           u64 nflat, const u64* vals, u64* flat) {
+  const u64 tile = blockIdx.x;
+  const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 packed = *reinterpret_cast<const u64*>(leaf_levels + s0);
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cnt += (((packed >> (8 * j)) & 0xff) <= thr && s0 + j < nflat) ? 1 : 0;
+  }
+  u32 total;
+  u64 idx = tile_offsets[tile] + block_excl_scan(cnt, &total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u64 s = s0 + j;
+    if (((packed >> (8 * j)) & 0xff) <= thr && s < nflat) ++idx;
+    flat[s] = (s < nflat && idx > 0) ? vals[idx - 1] : 0;
+  }
+}
+
+// tags (0 defined / 1 undefined) of a nested column from decoded level bytes
+__global__ void __launch_bounds__(kBlock) k_defined_from_levels(const u8* dlevels, u32 dmax,
+                                                                u64 nslots, u8* tags,
+                                                                u64* tile_counts) {
+  const u64 tile = blockIdx.x;
+  const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 packed = *reinterpret_cast<const u64*>(dlevels + s0);
+  u32 cnt = 0;
+  u64 out = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool def = (((packed >> (8 * j)) & 0xff) == dmax) && (s0 + j < nslots);
+    cnt += def ? 1 : 0;
+    out |= (u64) (def ? 0 : 1) << (8 * j);
+  }
+  *reinterpret_cast<u64*>(tags + s0) = out;
+  u32 total;
+  block_excl_scan(cnt, &total);
+  if (threadIdx.x == 0) tile_counts[tile] = total;
+}
+
 inline int grid_for(u64 n, int block = kBlock, int cap = 8192) {
   u64 g = (n + block - 1) / block;
   if (g < 1) g = 1;

@@ -487,8 +487,13 @@ int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user) {
   API_CATCH
 }
 
-int evql_query_column_count(const evql_query_t* q) { return int(q->select.size()); }
+int evql_query_column_count(const evql_query_t* q) {
+  // PartialGroupByExpression emits (key, data) string pairs (groupby.cc:484-491)
+  if (q->group_mode == EVQL_MODE_PARTIAL) return 2;
+  return int(q->select.size());
+}
 int evql_query_column_type(const evql_query_t* q, int idx) {
+  if (q->group_mode == EVQL_MODE_PARTIAL) return idx >= 0 && idx < 2 ? EVQL_T_STRING : -1;
   if (idx < 0 || size_t(idx) >= q->select.size()) return -1;
   return int(q->select[idx].return_type);
 }

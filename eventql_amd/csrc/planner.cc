@@ -283,6 +283,11 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     }
   }
   if (int(kp.states.size()) > kMaxStateWords) return unsup("too many aggregate state words");
+  // PartialGroupBy rows carry SHA1(tuple bytes): with a hashed identity the key
+  // values have to be re-read from the group's first row
+  if (plan->group_mode == EVQL_MODE_PARTIAL && kp.key_mode == KEY_HASHED) {
+    kp.need_first_row = true;
+  }
 
   kp.has_row_filter = plan->row_filter_bits != nullptr;
 

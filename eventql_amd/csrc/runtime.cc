@@ -726,12 +726,43 @@ static Value agg_value(const evql_query* q, const AggPlan& a, const uint64_t* st
   return v;
 }
 
+static void put_varuint(std::vector<uint8_t>* b, uint64_t v) {
+  do {
+    uint8_t x = v & 0x7f;
+    v >>= 7;
+    if (v) x |= 0x80;
+    b->push_back(x);
+  } while (v);
+}
+
+// instance_savestate of each aggregate: count / sum = LEB128 varuint
+// (aggregate.cc:55-57,171-173,207-209); build-supplied: sum_float64 = 8 raw
+// bytes, min/max/mean = varuint(non-null count) + 8 raw bytes
+static void save_state(const AggPlan& a, const uint64_t* st, std::vector<uint8_t>* out) {
+  const uint64_t w0 = st[a.first_word];
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(&w0);
+  switch (a.fn) {
+    case EVQL_AGG_COUNT:
+    case EVQL_AGG_SUM_UINT64:
+    case EVQL_AGG_SUM_INT64:
+      put_varuint(out, w0);
+      return;
+    case EVQL_AGG_SUM_FLOAT64:
+      out->insert(out->end(), p, p + 8);
+      return;
+    default:
+      put_varuint(out, st[a.first_word + 1]);
+      out->insert(out->end(), p, p + 8);
+  }
+}
+
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows) {
   if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
   const KernelPlan& kp = q->kp;
   evql_table* t = q->table;
   const size_t nsel = q->select.size();
-  q->out_cols.assign(nsel, std::vector<uint8_t>());
+  const bool partial = q->group_mode == EVQL_MODE_PARTIAL;
+  q->out_cols.assign(partial ? 2 : nsel, std::vector<uint8_t>());
   const size_t rw = size_t(kp.words_per_slot()) + 1;
   const uint32_t nc = uint32_t(kp.cols.size());
   size_t emitted = 0;
@@ -777,9 +808,14 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
       }
       have_inputs = true;
     }
+    std::vector<uint8_t> pdata;  // PARTIAL mode: concatenated saved states
     for (size_t i = 0; i < nsel; ++i) {
       const LoweredProgram& lp = q->select[i];
       Value out;
+      if (partial && lp.is_aggregate) {
+        save_state(kp.aggs[q->select_agg_index[i]], st, &pdata);
+        continue;
+      }
       if (lp.is_aggregate) {
         Value av = agg_value(q, kp.aggs[q->select_agg_index[i]], st);
         std::string e = eval_expr(lp.call, have_inputs ? sel_inputs : std::vector<Value>(), &av, &out);
@@ -797,12 +833,44 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
         std::string e = eval_expr(lp.call, have_inputs ? sel_inputs : std::vector<Value>(), nullptr, &out);
         if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
       }
-      append_svector(lp.return_type, out, &q->out_cols[i]);
+      if (partial) {
+        // SValue::encode (svalue.cc): u8 type, lenenc(value || tag bytes)
+        std::vector<uint8_t> enc;
+        append_svector(lp.return_type, out, &enc);
+        pdata.push_back(uint8_t(lp.return_type));
+        put_varuint(&pdata, enc.size());
+        pdata.insert(pdata.end(), enc.begin(), enc.end());
+      } else {
+        append_svector(lp.return_type, out, &q->out_cols[i]);
+      }
+    }
+    if (partial) {
+      // group key = SHA1 of the tuple bytes, LAST group expression first
+      // (groupby.cc:112-135: the VM stack grows downward)
+      std::vector<uint8_t> tuple;
+      for (size_t gi = q->group.size(); gi-- > 0;) {
+        Value gv;
+        if (kp.key_mode == KEY_EXACT) {
+          gv.type = q->group[gi].return_type;
+          gv.bits = kind == 2 ? 0 : ident;
+          gv.tag = kind == 2 ? EVQL_STAG_NULL : 0;
+        } else {
+          std::string e = eval_expr(q->group[gi].call, sel_inputs, nullptr, &gv);
+          if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+        }
+        append_svector(q->group[gi].return_type, gv, &tuple);
+      }
+      Sha1Digest d = sha1(tuple.data(), tuple.size());
+      Value kv, dv;
+      kv.str.assign(reinterpret_cast<const char*>(d.bytes), 20);
+      dv.str.assign(reinterpret_cast<const char*>(pdata.data()), pdata.size());
+      append_svector(EVQL_T_STRING, kv, &q->out_cols[0]);
+      append_svector(EVQL_T_STRING, dv, &q->out_cols[1]);
     }
     ++q->emit_pos;
     ++emitted;
   }
-  for (size_t i = 0; i < nsel; ++i) {
+  for (size_t i = 0; i < q->out_cols.size(); ++i) {
     cols[i].data = q->out_cols[i].data();
     cols[i].size = q->out_cols[i].size();
   }

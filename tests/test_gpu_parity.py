@@ -214,6 +214,29 @@ def test_row_ranges_partition_the_table(mixed):
     qb.close()
 
 
+def test_partial_group_by_wire_rows(mixed):
+    """EVQL_MODE_PARTIAL = PartialGroupByExpression::nextBatch (groupby.cc:438-472):
+    (SHA1 group key, concatenated saved states / encoded SValues), byte for byte"""
+    t, img, _ = mixed
+    for kw in (dict(select=[col("k"), sum_(col("a")), count(1)], group_by=[col("k")],
+                    where=col("a") >= 0),
+               dict(select=[col("k"), col("s"), count(1), sum_(col("b"))],
+                    group_by=[col("k"), col("s")]),
+               dict(select=[col("nb"), count(1), max_(col("a")), mean(col("a"))],
+                    group_by=[col("nb")]),
+               dict(select=[count(1), sum_(col("a"))])):
+        plan = Plan(T.MIXED_SCHEMA, mode=K.MODE_PARTIAL, **kw)
+        exp = O.oracle_run(img, plan)
+        q = t.query(plan)
+        got = q.run()
+        assert q.column_count() == 2 and got.types == [K.T_STRING, K.T_STRING]
+        e = {exp.keys[20 * i:20 * i + 20]: exp.columns[0][i] for i in range(exp.nrows)}
+        g = dict(got.rows())
+        assert len(g) == got.nrows == exp.nrows
+        assert g == e
+        q.close()
+
+
 def _small_table(ctx, cols, specs, n):
     w = E.Writer(specs)
     for s in specs:
