@@ -325,17 +325,7 @@ __global__ void __launch_bounds__(kBlock) k_synth(const SynthArgs* ap, u64 nchun
 // ---- nested (Dremel) scans ---------------------------------------------------------
 // level stream (bit-packed, width `bits`) -> one byte per slot, plus per-tile
 // counts of slots with level <= thr[c] for up to 4 thresholds (thr = 255 => skip)
-struct LevelCountArgs {
-  const u8* image;
-  const u64* pages;
-  u32 bits;
-  u64 nslots;     // slots to decode (stream capacity)
-  u8* levels;     // out, padded to a tile multiple
-  u64* counts[4];  // out: per tile
-  u32 thr[4];
-};
-
-__global__ void __launch_bounds__(kBlock) k_level_decode(LevelCountArgs a) {
+__global__ void __launch_bounds__(kBlock) k_level_decode(LevelDecodeArgs a) {
   const u64 tile = blockIdx.x;
   const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
   u32 cnt[4] = {0, 0, 0, 0};
@@ -345,7 +335,7 @@ __global__ void __launch_bounds__(kBlock) k_level_decode(LevelCountArgs a) {
     const u64 s = s0 + j;
     u32 lv = 0xff;
     if (s < a.nslots) {
-      lv = evql_bitpacked_rt(a.image, a.pages, a.bits, s);
+      lv = evql_bitpacked_rt(a.image, (const u64*) a.pages, a.bits, s);
 #pragma unroll
       for (int c = 0; c < 4; ++c) cnt[c] += (lv <= a.thr[c]) ? 1 : 0;
     }
@@ -360,6 +350,17 @@ __global__ void __launch_bounds__(kBlock) k_level_decode(LevelCountArgs a) {
     if (threadIdx.x == 0) a.counts[c][tile] = total;
   }
 }
+
+}  // namespace
+
+hipError_t launch_level_decode(const LevelDecodeArgs& a, hipStream_t s) {
+  const u64 ntiles = (a.nslots + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_level_decode, dim3((unsigned) ntiles), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+namespace {
 
 // first slot index at which the inclusive count of (level <= thr) exceeds
 // `target` (i.e. the start of record number `target`), given the scanned tile
@@ -527,6 +528,35 @@ hipError_t launch_string_hash(const uint8_t* image, const uint64_t* pages,
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_string_hash, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
                      (const u64*) pages, (const u64*) offsets, lens, (u64) n, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_find_nth(const uint8_t* levels, const uint64_t* tile_offsets, uint64_t nslots,
+                           uint32_t thr, uint64_t target, uint64_t* out, hipStream_t s) {
+  const u64 ntiles = (nslots + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_find_nth, dim3((unsigned) ntiles), dim3(kBlock), 0, s, levels,
+                     (const u64*) tile_offsets, (u64) ntiles, (u64) nslots, thr, (u64) target,
+                     (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_flatten_parent(const uint8_t* leaf_levels, const uint64_t* tile_offsets,
+                                 uint32_t thr, uint64_t nflat, const uint64_t* vals,
+                                 uint64_t* flat, hipStream_t s) {
+  const u64 ntiles = (nflat + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_flatten_parent, dim3((unsigned) ntiles), dim3(kBlock), 0, s, leaf_levels,
+                     (const u64*) tile_offsets, thr, (u64) nflat, (const u64*) vals, (u64*) flat);
+  return hipGetLastError();
+}
+
+hipError_t launch_defined_from_levels(const uint8_t* dlevels, uint32_t dmax, uint64_t nslots,
+                                      uint8_t* tags, uint64_t* tile_counts, hipStream_t s) {
+  const u64 ntiles = (nslots + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_defined_from_levels, dim3((unsigned) ntiles), dim3(kBlock), 0, s, dlevels,
+                     dmax, (u64) nslots, tags, (u64*) tile_counts);
   return hipGetLastError();
 }
 

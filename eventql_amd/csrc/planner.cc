@@ -84,7 +84,11 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     return Status::error(EVQL_ENOTSUP, m);
   };
 
-  if (plan->scan_mode != EVQL_SCAN_FLAT) return unsup("nested scans are not lowered yet");
+  const bool nested = plan->scan_mode == EVQL_SCAN_NESTED;
+  if (plan->scan_mode != EVQL_SCAN_FLAT && !nested) return Status::error(EVQL_EARG, "bad scan mode");
+  q->nested = nested;
+  if (nested && plan->row_filter_bits) return unsup("row filter on a nested scan");
+  if (nested && (plan->row_begin || plan->row_end)) return unsup("row range on a nested scan");
   if (plan->n_scan_columns > EVQL_MAX_COLS_HOST) return unsup("too many scan columns");
   if (plan->n_select == 0) return unsup("bare scans are not lowered (no GROUP BY / aggregate)");
 
@@ -104,7 +108,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
       // the reference would dereference a null reader here (CSTableScan.cc:747-751)
       return Status::error(EVQL_EARG, "column not found: " + c.name);
     }
-    if (cl->rlevel_max > 0) return unsup("repeated column in a flat scan: " + c.name);
+    // FastCSTableScan reads batch_size *values* of a repeated column and returns
+    // wrong rows (SURVEY.md header); the reference routes such scans through
+    // CSTableScan, i.e. EVQL_SCAN_NESTED
+    if (cl->rlevel_max > 0 && !nested) return unsup("repeated column in a flat scan: " + c.name);
     switch (c.stype) {
       case EVQL_T_NIL:
         return Status::error(EVQL_EARG, "illegal column type: NIL");
@@ -162,7 +169,28 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
         c.has_tags = true;
       }
     }
+    if (nested) {
+      // CSTableScan path: every column is flattened to one value per output row;
+      // undefined slots read as 0 with tag 0 (CSTableScan.cc:224-246)
+      if (c.string_hash) return unsup("string columns in nested scans are not lowered yet");
+      c.mode = ColAccess::SOA;
+      c.has_tags = false;
+    }
     kp.cols.push_back(c);
+  }
+  if (nested && plan->where) {
+    // after a row rejected by WHERE the reference resets parent values without
+    // re-reading them (CSTableScan.cc:501-512); only leaf-level-only scans are
+    // free of that history dependence
+    uint32_t lo = ~0u, hi = 0;
+    for (const auto& c : kp.cols) {
+      uint32_t rm = layout.columns[c.layout_index].rlevel_max;
+      lo = rm < lo ? rm : lo;
+      hi = rm > hi ? rm : hi;
+    }
+    if (!kp.cols.empty() && lo != hi) {
+      return unsup("WHERE over columns of different repetition depth in a nested scan");
+    }
   }
 
   // ---- programs ----------------------------------------------------------------------

@@ -218,6 +218,7 @@ evql_query::~evql_query() {
   if (d_status) hipFree(d_status);
   if (d_counters) hipFree(d_counters);
   if (d_row_filter) hipFree(d_row_filter);
+  for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
 }
@@ -411,6 +412,263 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
 }
 
 // ---------------------------------------------------------------------------
+// nested (Dremel) scans: CSTableScan::fetchNext with NO_AGGREGATION
+// (sql/CSTableScan.cc:187-541) as data-parallel passes.
+//
+// One output row per slot of the deepest referenced column (the "leaf").  A
+// column X at a shallower repetition depth repeats its current value, i.e. row j
+// reads X's slot  #{ i <= j : r_leaf[i] <= rlevel_max(X) } - 1.  Undefined slots
+// (d < dlevel_max) read as value 0 with tag 0 (an all-zero `SValue()`,
+// svalue.cc:154-160 -- NOT a NULL tag).  The number of real slots is where record
+// number `num_rows` would start (bit-packed streams are zero-padded).
+// ---------------------------------------------------------------------------
+static uint64_t level_stream_capacity(const std::vector<PageRef>& pages, uint32_t bits) {
+  if (bits == 0) return 0;
+  uint64_t blocks = 0;
+  for (size_t i = 0; i < pages.size(); ++i) {
+    uint64_t bytes = pages[i].size - (i == 0 ? 4 : 0);
+    blocks += bytes / (16ull * bits);
+  }
+  return blocks * 128;
+}
+
+static Status stream_bits(evql_table* t, const std::vector<PageRef>& pages, uint32_t* bits) {
+  uint32_t maxv = 0;
+  if (!pages.empty()) {
+    HIP_TRY(hipMemcpy(&maxv, t->d_image + pages[0].offset, 4, hipMemcpyDeviceToHost));
+  }
+  *bits = pages.empty() ? 0 : bitpack_width(maxv);
+  return Status();
+}
+
+// slot values of one (possibly repeated / optional) column: vals[slot] = defined
+// ? data value : 0, for every slot of its level streams (or `nslots` when the
+// column has no definition levels)
+static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, uint64_t** out_vals,
+                                 uint64_t* out_cap) {
+  evql_ctx* ctx = t->ctx;
+  hipStream_t s = ctx->stream;
+  const ColumnLayout& c = t->layout.columns[li];
+  // a column without definition levels is required and top-level: one slot per record
+  if (c.dlevel_max == 0) nslots_flat = t->layout.num_rows;
+  uint64_t cap = nslots_flat;
+  uint8_t* d_tags = nullptr;
+  uint64_t* d_tiles = nullptr;
+  uint64_t nvalues = nslots_flat;
+  if (c.dlevel_max > 0) {
+    uint32_t dbits = 0;
+    Status st = stream_bits(t, c.dlevel_pages, &dbits);
+    if (!st.ok()) return st;
+    cap = dbits ? level_stream_capacity(c.dlevel_pages, dbits) : nslots_flat;
+  }
+  const uint64_t capp = padded_rows(cap);
+  const uint64_t ntiles = (cap + kDecodeTile - 1) / kDecodeTile;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tags), capp));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tiles), (ntiles + 2) * 8));
+  if (c.dlevel_max > 0) {
+    uint32_t dbits = 0;
+    stream_bits(t, c.dlevel_pages, &dbits);
+    uint8_t* d_lv = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lv), capp));
+    HIP_TRY(hipMemsetAsync(d_lv, 0xff, capp, s));
+    if (dbits == 0) {
+      // every slot has definition level 0
+      HIP_TRY(hipMemsetAsync(d_lv, 0, capp, s));
+    } else {
+      LevelDecodeArgs la{};
+      la.image = t->d_image;
+      la.pages = t->d_pages[li][2];
+      la.bits = dbits;
+      la.nslots = cap;
+      la.levels = d_lv;
+      for (int k = 0; k < 4; ++k) la.thr[k] = 255;
+      HIP_TRY(launch_level_decode(la, s));
+    }
+    HIP_TRY(launch_defined_from_levels(d_lv, c.dlevel_max, cap, d_tags, d_tiles, s));
+    uint64_t* d_total = d_tiles + ntiles;
+    HIP_TRY(launch_exclusive_scan(d_tiles, ntiles, d_total, s));
+    HIP_TRY(hipMemcpyAsync(&nvalues, d_total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(d_lv);
+  } else {
+    HIP_TRY(hipMemsetAsync(d_tags, 0, capp, s));
+    std::vector<uint64_t> offs(ntiles + 1);
+    for (uint64_t i = 0; i <= ntiles; ++i) offs[i] = i * kDecodeTile;
+    HIP_TRY(hipMemcpyAsync(d_tiles, offs.data(), (ntiles + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  RtColumn src{};
+  src.pages = t->d_pages[li][0];
+  uint64_t* d_dense = nullptr;
+  switch (c.storage_type) {
+    case ColumnEncoding::UINT64_PLAIN:
+    case ColumnEncoding::FLOAT_IEEE754:
+      src.mode = ColAccess::PLAIN64;
+      break;
+    case ColumnEncoding::UINT32_PLAIN:
+      src.mode = ColAccess::PLAIN32;
+      break;
+    case ColumnEncoding::UINT32_BITPACKED:
+    case ColumnEncoding::BOOLEAN_BITPACKED: {
+      src.mode = ColAccess::BITPACKED;
+      Status st = stream_bits(t, c.data_pages, &src.bits);
+      if (!st.ok()) return st;
+      break;
+    }
+    case ColumnEncoding::UINT64_LEB128: {
+      const uint64_t nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
+      const uint64_t nchunks = (nbytes + kLebChunk - 1) / kLebChunk;
+      uint64_t* d_chunks = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_chunks), (nchunks + 1) * 8));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), std::max<uint64_t>(nvalues, 1) * 8));
+      if (nchunks) {
+        HIP_TRY(launch_leb128_count(t->d_image, t->d_pages[li][0], nbytes, d_chunks, s));
+        HIP_TRY(launch_exclusive_scan(d_chunks, nchunks, nullptr, s));
+        HIP_TRY(launch_leb128_decode(t->d_image, t->d_pages[li][0], nbytes, d_chunks, nvalues,
+                                     d_dense, s));
+      }
+      HIP_TRY(hipStreamSynchronize(s));
+      hipFree(d_chunks);
+      src.mode = ColAccess::SOA;
+      src.soa = d_dense;
+      break;
+    }
+    default:
+      return Status::error(EVQL_ENOTSUP, "unsupported nested column encoding");
+  }
+  uint64_t* d_vals = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vals), capp * 8));
+  HIP_TRY(hipMemsetAsync(d_vals, 0, capp * 8, s));
+  HIP_TRY(launch_expand_nullable(t->d_image, src, d_tags, d_tiles, cap, d_vals, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  hipFree(d_tags);
+  hipFree(d_tiles);
+  if (d_dense) hipFree(d_dense);
+  *out_vals = d_vals;
+  *out_cap = cap;
+  return Status();
+}
+
+static Status materialize_nested(evql_query* q) {
+  evql_table* t = q->table;
+  evql_ctx* ctx = q->ctx;
+  hipStream_t s = ctx->stream;
+  KernelPlan& kp = q->kp;
+  const uint64_t nrec = t->layout.num_rows;
+  q->nested_flat.assign(kp.cols.size(), nullptr);
+  if (kp.cols.empty()) {
+    q->nested_rows = nrec;  // fetchNextWithoutColumns: one row per record
+    return Status();
+  }
+  // leaf = deepest referenced column
+  int leaf = 0;
+  for (size_t i = 0; i < kp.cols.size(); ++i) {
+    if (t->layout.columns[kp.cols[i].layout_index].rlevel_max >
+        t->layout.columns[kp.cols[leaf].layout_index].rlevel_max) {
+      leaf = int(i);
+    }
+  }
+  const ColumnLayout& lc = t->layout.columns[kp.cols[leaf].layout_index];
+  uint64_t nflat = nrec;
+  uint8_t* d_leaf_levels = nullptr;
+  std::vector<uint32_t> thr_levels;       // distinct parent rlevel_max values
+  std::vector<uint64_t*> thr_offsets;     // scanned per-tile counts per threshold
+  if (lc.rlevel_max > 0) {
+    uint32_t rbits = 0;
+    Status st = stream_bits(t, lc.rlevel_pages, &rbits);
+    if (!st.ok()) return st;
+    const uint64_t cap = level_stream_capacity(lc.rlevel_pages, rbits);
+    const uint64_t capp = padded_rows(cap);
+    const uint64_t ntiles = (cap + kDecodeTile - 1) / kDecodeTile;
+    thr_levels.push_back(0);
+    for (const auto& c : kp.cols) {
+      uint32_t rm = t->layout.columns[c.layout_index].rlevel_max;
+      if (rm >= lc.rlevel_max) continue;
+      bool seen = false;
+      for (auto x : thr_levels) seen = seen || x == rm;
+      if (!seen) thr_levels.push_back(rm);
+    }
+    if (thr_levels.size() > 4) {
+      return Status::error(EVQL_ENOTSUP, "more than four repetition depths in one nested scan");
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_leaf_levels), capp));
+    HIP_TRY(hipMemsetAsync(d_leaf_levels, 0xff, capp, s));
+    LevelDecodeArgs la{};
+    la.image = t->d_image;
+    la.pages = t->d_pages[kp.cols[leaf].layout_index][1];
+    la.bits = rbits;
+    la.nslots = cap;
+    la.levels = d_leaf_levels;
+    for (int k = 0; k < 4; ++k) la.thr[k] = 255;
+    for (size_t k = 0; k < thr_levels.size(); ++k) {
+      uint64_t* d = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (ntiles + 2) * 8));
+      thr_offsets.push_back(d);
+      la.counts[k] = d;
+      la.thr[k] = thr_levels[k];
+    }
+    if (rbits == 0) {
+      return Status::error(EVQL_ENOTSUP, "repeated column without repetition levels");
+    }
+    HIP_TRY(launch_level_decode(la, s));
+    for (size_t k = 0; k < thr_levels.size(); ++k) {
+      HIP_TRY(launch_exclusive_scan(thr_offsets[k], ntiles, nullptr, s));
+    }
+    // number of real slots = start of record number `nrec`
+    uint64_t* d_n = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_n), 8));
+    HIP_TRY(hipMemcpyAsync(d_n, &cap, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_find_nth(d_leaf_levels, thr_offsets[0], cap, 0, nrec, d_n, s));
+    HIP_TRY(hipMemcpyAsync(&nflat, d_n, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(d_n);
+  }
+  q->nested_rows = nflat;
+  const uint64_t flatp = padded_rows(nflat);
+  for (size_t i = 0; i < kp.cols.size(); ++i) {
+    // the same column referenced twice shares one buffer
+    bool shared = false;
+    for (size_t j = 0; j < i; ++j) {
+      if (kp.cols[j].layout_index == kp.cols[i].layout_index) {
+        q->nested_flat[i] = q->nested_flat[j];
+        shared = true;
+      }
+    }
+    if (shared) continue;
+    const int li = kp.cols[i].layout_index;
+    const ColumnLayout& c = t->layout.columns[li];
+    uint64_t* d_vals = nullptr;
+    uint64_t cap = 0;
+    Status st = nested_slot_values(t, li, nflat, &d_vals, &cap);
+    if (!st.ok()) return st;
+    if (c.rlevel_max >= lc.rlevel_max) {
+      if (padded_rows(cap) < flatp) {
+        // level streams shorter than the leaf's: not the same ancestor chain
+        hipFree(d_vals);
+        return Status::error(EVQL_ENOTSUP, "nested columns from different repeated groups");
+      }
+      q->nested_flat[i] = d_vals;
+      q->nested_owned.push_back(d_vals);
+    } else {
+      size_t k = 0;
+      while (thr_levels[k] != c.rlevel_max) ++k;
+      uint64_t* d_flat = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flat), flatp * 8));
+      HIP_TRY(hipMemsetAsync(d_flat, 0, flatp * 8, s));
+      HIP_TRY(launch_flatten_parent(d_leaf_levels, thr_offsets[k], c.rlevel_max, nflat, d_vals,
+                                    d_flat, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      hipFree(d_vals);
+      q->nested_flat[i] = d_flat;
+      q->nested_owned.push_back(d_flat);
+    }
+  }
+  if (d_leaf_levels) hipFree(d_leaf_levels);
+  for (auto* p : thr_offsets) hipFree(p);
+  return Status();
+}
+
+// ---------------------------------------------------------------------------
 // query execution
 // ---------------------------------------------------------------------------
 static uint64_t word_identity(int op) {
@@ -428,8 +686,13 @@ static uint64_t word_identity(int op) {
 Status query_prepare(evql_query* q) {
   evql_table* t = q->table;
   evql_ctx* ctx = q->ctx;
+  if (q->nested) {
+    Status st = materialize_nested(q);
+    if (!st.ok()) return st;
+  }
   // resolve bit widths and materialise SoA columns
   for (auto& c : q->kp.cols) {
+    if (q->nested) break;
     const ColumnLayout& cl = t->layout.columns[c.layout_index];
     if (c.mode == ColAccess::BITPACKED) {
       uint32_t maxv = 0;
@@ -503,7 +766,7 @@ Status query_launch(evql_query* q) {
 
   HostArgs a{};
   a.image = t->d_image;
-  const uint64_t nrows = t->layout.num_rows;
+  const uint64_t nrows = q->nested ? q->nested_rows : t->layout.num_rows;
   a.row_begin = std::min(q->row_begin, nrows);
   a.row_end = q->row_end ? std::min(q->row_end, nrows) : nrows;
   const uint64_t T = uint64_t(kp.tile_rows());
@@ -519,7 +782,9 @@ Status query_launch(evql_query* q) {
     const ColAccess& c = kp.cols[i];
     a.col[i].pages = t->d_pages[c.layout_index][0];
     a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
-    if (c.mode == ColAccess::SOA) {
+    if (q->nested) {
+      a.col[i].soa = q->nested_flat[i];
+    } else if (c.mode == ColAccess::SOA) {
       const MaterializedColumn& m = t->materialized[c.name];
       a.col[i].soa = m.d_values;
       a.col[i].tags = m.d_tags;
@@ -635,7 +900,9 @@ static Status fetch_results(evql_query* q) {
       rc[c].pages = t->d_pages[ca.layout_index][0];
       rc[c].mode = ca.mode;
       rc[c].bits = ca.bits;
-      if (ca.mode == ColAccess::SOA) {
+      if (q->nested) {
+        rc[c].soa = q->nested_flat[c];
+      } else if (ca.mode == ColAccess::SOA) {
         const MaterializedColumn& m = t->materialized[ca.name];
         rc[c].soa = m.d_values;
         rc[c].tags = m.d_tags;

@@ -102,6 +102,11 @@ struct evql_query {
   std::vector<uint8_t> row_filter_host;
   uint64_t row_filter_len = 0;
   uint8_t* d_row_filter = nullptr;
+  // nested (Dremel) scans: flattened per-row SoA columns, one per scan column
+  bool nested = false;
+  uint64_t nested_rows = 0;
+  std::vector<uint64_t*> nested_flat;
+  std::vector<uint64_t*> nested_owned;
   std::string source;
   evql::Module module;
   // execution state

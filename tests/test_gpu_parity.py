@@ -237,6 +237,71 @@ def test_partial_group_by_wire_rows(mixed):
         q.close()
 
 
+def test_nested_scan_known_answers(ctx):
+    """Dremel flattening (CSTableScan, NO_AGGREGATION) on the device: the
+    Runtime_test.cc:175-375 answers on the reference's fixture (re-encoded as
+    v0.2.0), each also compared with the oracle"""
+    import nested_tables as N
+    img = N.testtbl_v2()
+    t = ctx.open_image(img)
+    S = N.NESTED_SCHEMA
+    tm = col("time")
+    sq_time = col("event.search_query.time")
+    nitems = col("event.search_query.num_result_items")
+    pos = col("event.search_query.result_items.position")
+    clicked = col("event.search_query.result_items.clicked")
+    cases = [
+        (dict(select=[count(1)]), [(213,)]),                             # no columns: per record
+        (dict(select=[count(sq_time)]), [(773,)]),                       # 704 defined + 69 empty
+        (dict(select=[count(1)], where=sq_time > 0), [(704,)]),
+        (dict(select=[sum_(nitems)]), [(24793,)]),
+        (dict(select=[count(1), sum_(If(clicked, 1, 0))], where=pos.eq(6)), [(688, 2)]),
+        # parents repeat per leaf slot: 24866 flattened rows
+        (dict(select=[count(tm), count(sq_time), sum_(nitems), count(pos)]), None),
+        (dict(select=[pos, count(1), sum_(nitems), max_(tm)], group_by=[pos]), None),
+        (dict(select=[nitems, count(1), sum_(pos)], group_by=[nitems]), None),
+    ]
+    for kw, known in cases:
+        plan = Plan(S, scan_mode=K.SCAN_NESTED, **kw)
+        exp = O.oracle_run(img, plan)
+        if known is not None:
+            assert exp.rows() == known
+        q = t.query(plan)
+        got = q.run()
+        T.compare_results(got.rows(), exp.rows(), exp.types, key_cols=len(kw.get("group_by", [])))
+        assert q.stats()["rows_passed"] == exp.rows_passed
+        q.close()
+    # not lowerable: WHERE mixing repetition depths (the reference's reset quirk)
+    with pytest.raises(E.EvqlError) as ei:
+        t.query(Plan(S, select=[count(1)], where=(pos > 3) & (nitems > 10),
+                     scan_mode=K.SCAN_NESTED))
+    assert ei.value.code == K.EVQL_ENOTSUP
+    t.close()
+
+
+def test_nested_scan_synthetic_items(ctx):
+    """config-5 shape: REPEATED RECORD items{position, price}, 0..8 per record"""
+    import nested_tables as N
+    img, st = N.items_table(100_000)
+    t = ctx.open_image(img)
+    S = N.ITEMS_SCHEMA
+    pos, price, rid, score = col("items.position"), col("items.price"), col("id"), col("score")
+    for kw in (dict(select=[count(1), sum_(price), sum_(pos)]),
+               dict(select=[count(1), sum_(price)], where=pos > 0),
+               dict(select=[pos, count(1), sum_(price), min_(price), max_(price)], group_by=[pos]),
+               dict(select=[pos, count(1), sum_(rid), sum_(score)], group_by=[pos]),
+               dict(select=[count(1), sum_(rid)])):
+        plan = Plan(S, scan_mode=K.SCAN_NESTED, **kw)
+        exp = O.oracle_run(img, plan)
+        q = t.query(plan)
+        got = q.run()
+        T.compare_results(got.rows(), exp.rows(), exp.types, key_cols=len(kw.get("group_by", [])))
+        q.close()
+    got = t.query(Plan(S, select=[count(1), sum_(price), sum_(pos)], scan_mode=K.SCAN_NESTED)).run()
+    assert got.rows() == [(st["total"], st["sum_price"], st["sum_pos"])]
+    t.close()
+
+
 def _small_table(ctx, cols, specs, n):
     w = E.Writer(specs)
     for s in specs:

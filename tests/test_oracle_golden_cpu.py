@@ -249,3 +249,47 @@ def test_sql_00014_group_by_first_row(built, tmp_path):
     assert exp[0] == "city;customername"
     exp_rows = sorted(tuple(x.split(";")) for x in exp[1:] if x)
     assert got == exp_rows
+
+
+def test_v2_transcode_of_the_nested_fixture_keeps_the_known_answers(built):
+    """testtbl.cst re-encoded as v0.2.0 by the product's writer (same r/d/value
+    triples) still gives the Runtime_test.cc answers through the oracle -- and,
+    where built, is read identically by the reference's own reader"""
+    import nested_tables as N
+    img = N.testtbl_v2()
+    S = N.NESTED_SCHEMA
+    sq_time = col("event.search_query.time")
+    nitems = col("event.search_query.num_result_items")
+    pos = col("event.search_query.result_items.position")
+    clicked = col("event.search_query.result_items.clicked")
+    assert O.oracle_run(img, Plan(S, select=[sum_(nitems)], scan_mode=K.SCAN_NESTED)).rows() == \
+        [(24793,)]
+    assert O.oracle_run(img, Plan(S, scan_select=[lit(1), sq_time, nitems, pos],
+                                  scan_mode=K.SCAN_NESTED)).nrows == 24866
+    assert O.oracle_run(img, Plan(S, select=[count(1), sum_(If(clicked, 1, 0))], where=pos.eq(6),
+                                  scan_mode=K.SCAN_NESTED)).rows() == [(688, 2)]
+    assert O.oracle_run(img, Plan(S, select=[count(1)])).rows() == [(213,)]
+    if O.have_ref():
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".cst") as f:
+            f.write(img)
+            f.flush()
+            a = O.TableReader(f.name, "ref").read("event.search_query.result_items.position",
+                                                   24866, "uint")
+            b = O.TableReader(os.path.join(T.GOLDEN, "testtbl.cst"), "ref").read(
+                "event.search_query.result_items.position", 24866, "uint")
+            for x, y in zip(a, b):
+                assert (x == y).all()
+
+
+def test_synthetic_items_table_against_numpy(built):
+    import nested_tables as N
+    img, st = N.items_table(20_000)
+    S = N.ITEMS_SCHEMA
+    r = O.oracle_run(img, Plan(S, select=[count(1), sum_(col("items.price")),
+                                          sum_(col("items.position"))],
+                               scan_mode=K.SCAN_NESTED))
+    assert r.rows() == [(st["total"], st["sum_price"], st["sum_pos"])]
+    r = O.oracle_run(img, Plan(S, select=[count(1)], where=col("items.position") > 0,
+                               scan_mode=K.SCAN_NESTED))
+    assert r.rows() == [(st["n_items"],)]
