@@ -200,13 +200,13 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   s << "#define EVQL_NSTATE " << NW << "\n";
   s << "#define EVQL_GSTRIDE (A.gcap + 8)\n\n";
 
-  s << "struct EvqlAcc {\n  u64 passed;\n";
+  s << "struct EvqlAcc {\n  u64 passed;\n  u64 spilled;\n";
   if (!grouped) s << "  u64 w[" << (NW > 0 ? NW : 1) << "];\n";
   s << "};\n\n";
 
   // ---- per-row function ------------------------------------------------------
   s << "__device__ __forceinline__ void evql_row(const EvqlArgs& A, u64* lds, EvqlAcc& acc,\n"
-       "                                         const u64 row, const bool valid";
+       "                                         const bool bypass, const u64 row, const bool valid";
   for (int i = 0; i < NC; ++i) s << ", const u64 r" << i << ", const u32 g" << i;
   s << ") {\n";
   s << "  if (!valid) return;\n";
@@ -329,14 +329,20 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     }
   } else {
     if (S > 0) {
-      s << "  int s;\n";
-      s << "  if (knull) { s = EVQL_LDS_SLOTS + 1; lds[s] = 0; }\n";
-      s << "  else if (ident == EVQL_EMPTY) { s = EVQL_LDS_SLOTS; lds[s] = 0; }\n";
-      s << "  else s = evql_lds_find<16>(lds, EVQL_LDS_SLOTS - 1, ident, (u32) evql_mix64(ident));\n";
-      s << "  if (s >= 0) {\n";
-      emit_updates("lds", "EVQL_LSTRIDE", "s", "    ");
-      s << "    return;\n  }\n";
-      s << "  atomicAdd(&A.counters[1], 1ull);\n";
+      // `bypass`: this workgroup has seen so many rows that found no LDS slot that
+      // the table is evidently too small for the data (high cardinality with an
+      // unknown hint): stop probing it, aggregate straight into the HBM table
+      s << "  if (!bypass) {\n";
+      s << "    int s;\n";
+      s << "    if (knull) { s = EVQL_LDS_SLOTS + 1; lds[s] = 0; }\n";
+      s << "    else if (ident == EVQL_EMPTY) { s = EVQL_LDS_SLOTS; lds[s] = 0; }\n";
+      s << "    else s = evql_lds_find<16>(lds, EVQL_LDS_SLOTS - 1, ident, (u32) evql_mix64(ident));\n";
+      s << "    if (s >= 0) {\n";
+      emit_updates("lds", "EVQL_LSTRIDE", "s", "      ");
+      s << "      return;\n    }\n";
+      s << "    atomicAdd(reinterpret_cast<u32*>(&lds[EVQL_WORDS * EVQL_LSTRIDE]), 1u);\n";
+      s << "  }\n";
+      s << "  acc.spilled += 1;\n";
     }
     s << "  i64 gs;\n";
     s << "  if (knull) { gs = (i64) A.gcap + 1; A.gtab[gs] = 0; }\n";
@@ -351,7 +357,8 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   s << "extern \"C\" __global__ void __launch_bounds__(EVQL_BLOCK) evql_scan_agg(const EvqlArgs A) {\n";
   s << "  const u32 tid = threadIdx.x;\n";
   if (grouped && S > 0) {
-    s << "  __shared__ u64 lds[EVQL_WORDS * EVQL_LSTRIDE];\n";
+    s << "  __shared__ u64 lds[EVQL_WORDS * EVQL_LSTRIDE + 1];\n";
+    s << "  if (tid == 0) lds[EVQL_WORDS * EVQL_LSTRIDE] = 0;  // rows that found no LDS slot\n";
     s << "  for (u32 i = tid; i < EVQL_LSTRIDE; i += EVQL_BLOCK) {\n";
     s << "    lds[i] = EVQL_EMPTY;\n";
     if (kp.need_first_row) s << "    lds[1 * EVQL_LSTRIDE + i] = 0xFFFFFFFFFFFFFFFFull;\n";
@@ -363,13 +370,25 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   } else {
     s << "  u64* lds = nullptr;\n";
   }
-  s << "  EvqlAcc acc;\n  acc.passed = 0;\n";
+  s << "  EvqlAcc acc;\n  acc.passed = 0;\n  acc.spilled = 0;\n";
   if (!grouped) {
     for (int w = 0; w < NW; ++w) {
       s << "  acc.w[" << w << "] = evql_op_identity<" << op_name(kp.states[w].op) << ">();\n";
     }
   }
   s << "  for (u64 t = blockIdx.x; t < A.ntiles; t += gridDim.x) {\n";
+  if (grouped) {
+    // a full HBM table makes the whole launch void (the host grows it and runs
+    // again): stop scanning as soon as any workgroup has reported it
+    s << "    if (__hip_atomic_load(&A.status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & "
+         "EVQL_ST_TABLE_FULL) break;\n";
+  }
+  if (grouped && S > 0) {
+    s << "    const bool bypass = *reinterpret_cast<volatile u32*>(&lds[EVQL_WORDS * EVQL_LSTRIDE]) "
+         ">= 4u * EVQL_BLOCK;\n";
+  } else {
+    s << "    const bool bypass = false;\n";
+  }
   s << "    const u64 base = (A.tile0 + t) * (u64) EVQL_TILE_ROWS;\n";
   for (int i = 0; i < NC; ++i) {
     s << "    u64 x" << i << "[EVQL_UNROLL][2]; u32 y" << i << "[EVQL_UNROLL][2];\n";
@@ -408,7 +427,7 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   s << "#pragma unroll\n    for (int u = 0; u < EVQL_UNROLL; ++u) {\n";
   s << "      const u64 r = base + ((u64) (u * EVQL_BLOCK) + tid) * 2;\n";
   for (int j = 0; j < 2; ++j) {
-    s << "      evql_row(A, lds, acc, r + " << j << ", (r + " << j << " >= A.row_begin) && (r + " << j
+    s << "      evql_row(A, lds, acc, bypass, r + " << j << ", (r + " << j << " >= A.row_begin) && (r + " << j
       << " < A.row_end)";
     for (int i = 0; i < NC; ++i) s << ", x" << i << "[u][" << j << "], y" << i << "[u][" << j << "]";
     s << ");\n";
@@ -417,7 +436,9 @@ std::string generate_kernel_source(const KernelPlan& kp) {
 
   // ---- epilogue ------------------------------------------------------------------
   s << "  {\n    const u64 p = evql_wave_reduce<EVQL_OP_ADD_U64>(acc.passed);\n";
-  s << "    if ((tid & 63u) == 0 && p) atomicAdd(&A.counters[0], p);\n  }\n";
+  s << "    if ((tid & 63u) == 0 && p) atomicAdd(&A.counters[0], p);\n";
+  s << "    const u64 sp = evql_wave_reduce<EVQL_OP_ADD_U64>(acc.spilled);\n";
+  s << "    if ((tid & 63u) == 0 && sp) atomicAdd(&A.counters[1], sp);\n  }\n";
   if (!grouped) {
     // block reduction of the register accumulators, one atomic per word per block
     s << "  __shared__ u64 red[(EVQL_BLOCK / 64) * " << (NW + 1) << "];\n";

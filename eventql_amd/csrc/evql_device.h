@@ -250,11 +250,16 @@ __device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32
 
 // global (HBM) table.  Keys never change once written, so a stale plain read
 // can only observe EMPTY, which the CAS then corrects.
+#define EVQL_GTAB_MAX_PROBE 128
 __device__ __forceinline__ i64 evql_gtab_find(u64* keys, u64 cap, u64 ident, u64 h) {
   const u64 mask = cap - 1;
   u64 s = h & mask;
+  // the host sizes the table for a load factor <= 1/4, where a chain of 128 is
+  // (practically) impossible; running into one means the table is too small:
+  // report TABLE_FULL and let the host grow it instead of crawling through it
+  const u64 maxp = cap < EVQL_GTAB_MAX_PROBE ? cap : EVQL_GTAB_MAX_PROBE;
 #pragma unroll 1
-  for (u64 probe = 0; probe < cap; ++probe) {
+  for (u64 probe = 0; probe < maxp; ++probe) {
     u64 cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == ident) return (i64) s;
     if (cur == EVQL_EMPTY) {
