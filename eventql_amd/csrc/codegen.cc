@@ -209,9 +209,12 @@ std::string generate_kernel_source(const KernelPlan& kp) {
        "                                         const bool bypass, const u64 row, const bool valid";
   for (int i = 0; i < NC; ++i) s << ", const u64 r" << i << ", const u32 g" << i;
   s << ") {\n";
-  s << "  if (!valid) return;\n";
+  // The function is written without early returns: every lane of the wave
+  // reaches the update section together, so that wave-level cooperation
+  // (ballot / shuffle reductions over lanes that hit the same slot) is legal.
+  s << "  bool live = valid;\n";
   if (kp.has_row_filter) {
-    s << "  if (!evql_row_filter(A.row_filter, A.row_filter_len, row)) return;\n";
+    s << "  live = live && evql_row_filter(A.row_filter, A.row_filter_len, row);\n";
   }
   for (int i = 0; i < NC; ++i) {
     const ColAccess& c = kp.cols[i];
@@ -229,32 +232,15 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "  (void) c" << i << "; (void) g" << i << ";\n";
   }
   Emitter em;
+  em.ind = "    ";
   if (kp.where) {
+    s << "  if (live) {\n";
     Val p = em.emit(kp.where);
     s << em.o.str();
     em.o.str("");
-    s << "  if (!" << p.v << ") return;\n";
+    s << "    live = " << p.v << ";\n  }\n";
   }
-  s << "  acc.passed += 1;\n";
-
-  // group key -> ident / knull
-  if (kp.key_mode == KEY_EXACT) {
-    Val k = em.emit(kp.group[0]);
-    s << em.o.str();
-    em.o.str("");
-    s << "  const u64 ident = " << Emitter::as_bits(k) << ";\n";
-    s << "  const bool knull = (" << k.g << " & 1u) != 0;\n";
-  } else if (kp.key_mode == KEY_HASHED) {
-    s << "  u64 ident = 0x243f6a8885a308d3ull;\n";
-    for (const auto& g : kp.group) {
-      Val k = em.emit(g);
-      s << em.o.str();
-      em.o.str("");
-      s << "  ident = evql_hash_combine(ident, " << Emitter::as_bits(k) << ");\n";
-      s << "  ident = evql_hash_combine(ident, (u64) (" << k.g << " & 1u));\n";
-    }
-    s << "  const bool knull = false;\n";
-  }
+  s << "  acc.passed += live ? 1 : 0;\n";
 
   // aggregate arguments -> list of word updates
   struct Upd {
@@ -264,6 +250,33 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     std::string cond;  // "" = unconditional
   };
   std::vector<Upd> upd;
+  const size_t nupd_words = [&] {
+    size_t n = 0;
+    for (const auto& a : kp.aggs) n += size_t(a.nwords);
+    return n;
+  }();
+  s << "  u64 ident = 0; bool knull = false;\n";
+  for (size_t i = 0; i < nupd_words; ++i) {
+    s << "  u64 ub" << i << " = 0; bool uc" << i << " = false;\n";
+  }
+  s << "  if (live) {\n";
+  // group key -> ident / knull
+  if (kp.key_mode == KEY_EXACT) {
+    Val k = em.emit(kp.group[0]);
+    s << em.o.str();
+    em.o.str("");
+    s << "    ident = " << Emitter::as_bits(k) << ";\n";
+    s << "    knull = (" << k.g << " & 1u) != 0;\n";
+  } else if (kp.key_mode == KEY_HASHED) {
+    s << "    ident = 0x243f6a8885a308d3ull;\n";
+    for (const auto& g : kp.group) {
+      Val k = em.emit(g);
+      s << em.o.str();
+      em.o.str("");
+      s << "    ident = evql_hash_combine(ident, " << Emitter::as_bits(k) << ");\n";
+      s << "    ident = evql_hash_combine(ident, (u64) (" << k.g << " & 1u));\n";
+    }
+  }
   for (const auto& a : kp.aggs) {
     Val v{"0", "0u", EVQL_T_NIL};
     if (a.arg) {
@@ -273,16 +286,25 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     }
     const std::string notnull = "((" + v.g + " & 1u) == 0)";
     const int w0 = a.first_word;
+    auto push = [&](int word, int op, const std::string& bits, const std::string& cond) {
+      const size_t i = upd.size();
+      s << "    ub" << i << " = " << bits << "; uc" << i << " = " << (cond.empty() ? "true" : cond)
+        << ";\n";
+      char b[16], c[16];
+      snprintf(b, sizeof(b), "ub%zu", i);
+      snprintf(c, sizeof(c), "uc%zu", i);
+      upd.push_back({word, op, b, c});
+    };
     switch (a.fn) {
       case EVQL_AGG_COUNT:
-        upd.push_back({w0, 0, "1ull", ""});
+        push(w0, 0, "1ull", "");
         break;
       case EVQL_AGG_SUM_UINT64:
       case EVQL_AGG_SUM_INT64:
-        upd.push_back({w0, 0, Emitter::as_bits(v), ""});
+        push(w0, 0, Emitter::as_bits(v), "");
         break;
       case EVQL_AGG_SUM_FLOAT64:
-        upd.push_back({w0, 1, Emitter::as_bits(v), ""});
+        push(w0, 1, Emitter::as_bits(v), "");
         break;
       case EVQL_AGG_MIN_UINT64:
       case EVQL_AGG_MAX_UINT64:
@@ -290,21 +312,22 @@ std::string generate_kernel_source(const KernelPlan& kp) {
       case EVQL_AGG_MAX_INT64:
       case EVQL_AGG_MIN_FLOAT64:
       case EVQL_AGG_MAX_FLOAT64:
-        upd.push_back({w0, kp.states[w0].op, Emitter::as_bits(v), notnull});
-        upd.push_back({w0 + 1, 0, "1ull", notnull});
+        push(w0, kp.states[w0].op, Emitter::as_bits(v), notnull);
+        push(w0 + 1, 0, "1ull", notnull);
         break;
       case EVQL_AGG_MEAN_UINT64:
       case EVQL_AGG_MEAN_INT64:
       case EVQL_AGG_MEAN_FLOAT64: {
         std::string d = a.fn == EVQL_AGG_MEAN_FLOAT64 ? v.v : "((double) " + v.v + ")";
-        upd.push_back({w0, 1, "evql_f64_bits(" + d + ")", notnull});
-        upd.push_back({w0 + 1, 0, "1ull", notnull});
+        push(w0, 1, "evql_f64_bits(" + d + ")", notnull);
+        push(w0 + 1, 0, "1ull", notnull);
         break;
       }
       default:
         break;
     }
   }
+  s << "  }\n";
 
   auto emit_updates = [&](const char* base, const char* stride, const char* slot,
                           const char* indent) {
@@ -313,43 +336,74 @@ std::string generate_kernel_source(const KernelPlan& kp) {
         << slot << "], row);\n";
     }
     for (const auto& u : upd) {
-      s << indent;
-      if (!u.cond.empty()) s << "if " << u.cond << " ";
-      s << "evql_atomic<" << op_name(u.op) << ">(&" << base << "[" << (SB + u.word) << " * "
-        << stride << " + " << slot << "], " << u.bits << ");\n";
+      s << indent << "if (" << u.cond << ") evql_atomic<" << op_name(u.op) << ">(&" << base << "["
+        << (SB + u.word) << " * " << stride << " + " << slot << "], " << u.bits << ");\n";
     }
   };
 
   if (!grouped) {
     for (const auto& u : upd) {
-      s << "  ";
-      if (!u.cond.empty()) s << "if " << u.cond << " ";
-      s << "acc.w[" << u.word << "] = evql_combine<" << op_name(u.op) << ">(acc.w[" << u.word
-        << "], " << u.bits << ");\n";
+      s << "  if (" << u.cond << ") acc.w[" << u.word << "] = evql_combine<" << op_name(u.op)
+        << ">(acc.w[" << u.word << "], " << u.bits << ");\n";
     }
   } else {
     if (S > 0) {
       // `bypass`: this workgroup has seen so many rows that found no LDS slot that
       // the table is evidently too small for the data (high cardinality with an
       // unknown hint): stop probing it, aggregate straight into the HBM table
-      s << "  if (!bypass) {\n";
-      s << "    int s;\n";
+      s << "  int s = -1;\n";
+      s << "  if (live && !bypass) {\n";
       s << "    if (knull) { s = EVQL_LDS_SLOTS + 1; lds[s] = 0; }\n";
       s << "    else if (ident == EVQL_EMPTY) { s = EVQL_LDS_SLOTS; lds[s] = 0; }\n";
       s << "    else s = evql_lds_find<16>(lds, EVQL_LDS_SLOTS - 1, ident, (u32) evql_mix64(ident));\n";
-      s << "    if (s >= 0) {\n";
-      emit_updates("lds", "EVQL_LSTRIDE", "s", "      ");
-      s << "      return;\n    }\n";
-      s << "    atomicAdd(reinterpret_cast<u32*>(&lds[EVQL_WORDS * EVQL_LSTRIDE]), 1u);\n";
+      s << "    if (s < 0) atomicAdd(reinterpret_cast<u32*>(&lds[EVQL_WORDS * EVQL_LSTRIDE]), 1u);\n";
       s << "  }\n";
-      s << "  acc.spilled += 1;\n";
+      // Wave-level pre-aggregation ("peel"): when many lanes of the wave hit the
+      // same slot -- a handful of groups, or one dominant key -- their LDS atomics
+      // on one address would serialise.  Up to four times, the slot of the first
+      // pending lane is broadcast, the lanes that share it are found with a ballot,
+      // and if they are at least 12 their contributions are reduced across the
+      // wave with shuffles so that ONE lane issues ONE atomic per state word.
+      s << "  bool pend = s >= 0;\n";
+      s << "#pragma unroll 1\n";
+      s << "  for (int round = 0; round < 4; ++round) {\n";
+      s << "    const u64 pm = __ballot(pend);\n";
+      s << "    if (pm == 0) break;\n";
+      s << "    const int leader = __ffsll((long long) pm) - 1;\n";
+      s << "    const int s0 = __shfl(s, leader, 64);\n";
+      s << "    const bool mine = pend && s == s0;\n";
+      s << "    const u64 same = __ballot(mine);\n";
+      s << "    if (__popcll(same) < 12) break;\n";
+      if (kp.need_first_row) {
+        s << "    { const u64 v = evql_wave_reduce<EVQL_OP_MIN_U64>(mine ? row : 0xFFFFFFFFFFFFFFFFull);\n";
+        s << "      if ((int) (threadIdx.x & 63u) == leader) evql_atomic<EVQL_OP_MIN_U64>(&lds[1 * EVQL_LSTRIDE + s0], v); }\n";
+      }
+      for (const auto& u : upd) {
+        s << "    { const u64 v = evql_wave_reduce<" << op_name(u.op) << ">((mine && " << u.cond
+          << ") ? " << u.bits << " : evql_op_identity<" << op_name(u.op) << ">());\n";
+        s << "      const bool anyc = __ballot(mine && " << u.cond << ") != 0;\n";
+        s << "      if ((int) (threadIdx.x & 63u) == leader && anyc) evql_atomic<" << op_name(u.op)
+          << ">(&lds[" << (SB + u.word) << " * EVQL_LSTRIDE + s0], v); }\n";
+      }
+      s << "    pend = pend && !mine;\n";
+      s << "  }\n";
+      s << "  if (pend) {\n";
+      emit_updates("lds", "EVQL_LSTRIDE", "s", "    ");
+      s << "  }\n";
+      s << "  const bool spill = live && s < 0;\n";
+      s << "  acc.spilled += spill ? 1 : 0;\n";
+    } else {
+      s << "  const bool spill = live;\n";
     }
-    s << "  i64 gs;\n";
-    s << "  if (knull) { gs = (i64) A.gcap + 1; A.gtab[gs] = 0; }\n";
-    s << "  else if (ident == EVQL_EMPTY) { gs = (i64) A.gcap; A.gtab[gs] = 0; }\n";
-    s << "  else gs = evql_gtab_find(A.gtab, A.gcap, ident, evql_mix64(ident));\n";
-    s << "  if (gs < 0) { atomicOr(&A.status[0], EVQL_ST_TABLE_FULL); return; }\n";
-    emit_updates("A.gtab", "EVQL_GSTRIDE", "gs", "  ");
+    s << "  if (spill) {\n";
+    s << "    i64 gs;\n";
+    s << "    if (knull) { gs = (i64) A.gcap + 1; A.gtab[gs] = 0; }\n";
+    s << "    else if (ident == EVQL_EMPTY) { gs = (i64) A.gcap; A.gtab[gs] = 0; }\n";
+    s << "    else gs = evql_gtab_find(A.gtab, A.gcap, ident, evql_mix64(ident));\n";
+    s << "    if (gs < 0) { atomicOr(&A.status[0], EVQL_ST_TABLE_FULL); }\n";
+    s << "    else {\n";
+    emit_updates("A.gtab", "EVQL_GSTRIDE", "gs", "      ");
+    s << "    }\n  }\n";
   }
   s << "}\n\n";
 

@@ -332,7 +332,11 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     uint64_t smax = 256;
     while ((smax * 2 + 2) * 8 * W <= 150 * 1024) smax <<= 1;
     const uint64_t hint = plan->groups_hint;
-    if (hint != 0 && hint * 2 > smax) {
+    // Dense keys are placed by identity, so even `hint` close to the slot count
+    // works (4000 dense groups in 4096 slots: 0.63 ms vs 24 ms HBM-only for 2e8
+    // rows); a workgroup whose table does thrash switches itself to the HBM
+    // table (`bypass`).  Only far beyond the LDS capacity is the table skipped.
+    if (hint > 8 * smax) {
       kp.lds_slots = 0;  // high cardinality: aggregate straight into the HBM table
       kp.block = 256;
     } else {
