@@ -200,9 +200,56 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   s << "#define EVQL_NSTATE " << NW << "\n";
   s << "#define EVQL_GSTRIDE (A.gcap + 8)\n\n";
 
+  // update words of one row (count / sum / min / max state words), in order
+  struct UpdWord {
+    int word;
+    int op;
+  };
+  std::vector<UpdWord> updw;
+  for (const auto& a : kp.aggs) {
+    switch (a.fn) {
+      case EVQL_AGG_COUNT:
+      case EVQL_AGG_SUM_UINT64:
+      case EVQL_AGG_SUM_INT64:
+        updw.push_back({a.first_word, 0});
+        break;
+      case EVQL_AGG_SUM_FLOAT64:
+        updw.push_back({a.first_word, 1});
+        break;
+      case EVQL_AGG_MEAN_UINT64:
+      case EVQL_AGG_MEAN_INT64:
+      case EVQL_AGG_MEAN_FLOAT64:
+        updw.push_back({a.first_word, 1});
+        updw.push_back({a.first_word + 1, 0});
+        break;
+      default:
+        updw.push_back({a.first_word, kp.states[a.first_word].op});
+        updw.push_back({a.first_word + 1, 0});
+    }
+  }
   s << "struct EvqlAcc {\n  u64 passed;\n  u64 spilled;\n";
   if (!grouped) s << "  u64 w[" << (NW > 0 ? NW : 1) << "];\n";
+  if (grouped && S > 0) {
+    s << "  int rslot;\n  u64 rfirst;\n  u64 rw[" << (updw.empty() ? 1 : updw.size()) << "];\n";
+  }
   s << "};\n\n";
+  if (grouped && S > 0) {
+    // fold the lane-private run accumulators into the LDS table (wave-converged)
+    s << "__device__ __forceinline__ void evql_flush_private(u64* lds, EvqlAcc& acc) {\n";
+    s << "  if (acc.rslot >= 0) {\n";
+    if (kp.need_first_row) {
+      s << "    { const u64 v = evql_wave_reduce<EVQL_OP_MIN_U64>(acc.rfirst);\n";
+      s << "      if ((threadIdx.x & 63u) == 0) evql_atomic<EVQL_OP_MIN_U64>(&lds[1 * EVQL_LSTRIDE + acc.rslot], v); }\n";
+      s << "    acc.rfirst = 0xFFFFFFFFFFFFFFFFull;\n";
+    }
+    for (size_t i = 0; i < updw.size(); ++i) {
+      s << "    { const u64 v = evql_wave_reduce<" << op_name(updw[i].op) << ">(acc.rw[" << i << "]);\n";
+      s << "      if ((threadIdx.x & 63u) == 0) evql_atomic<" << op_name(updw[i].op) << ">(&lds["
+        << (SB + updw[i].word) << " * EVQL_LSTRIDE + acc.rslot], v); }\n";
+      s << "    acc.rw[" << i << "] = evql_op_identity<" << op_name(updw[i].op) << ">();\n";
+    }
+    s << "  }\n}\n\n";
+  }
 
   // ---- per-row function ------------------------------------------------------
   s << "__device__ __forceinline__ void evql_row(const EvqlArgs& A, u64* lds, EvqlAcc& acc,\n"
@@ -358,35 +405,31 @@ std::string generate_kernel_source(const KernelPlan& kp) {
       s << "    else s = evql_lds_find<16>(lds, EVQL_LDS_SLOTS - 1, ident, (u32) evql_mix64(ident));\n";
       s << "    if (s < 0) atomicAdd(reinterpret_cast<u32*>(&lds[EVQL_WORDS * EVQL_LSTRIDE]), 1u);\n";
       s << "  }\n";
-      // Wave-level pre-aggregation ("peel"): when many lanes of the wave hit the
-      // same slot -- a handful of groups, or one dominant key -- their LDS atomics
-      // on one address would serialise.  Up to four times, the slot of the first
-      // pending lane is broadcast, the lanes that share it are found with a ballot,
-      // and if they are at least 12 their contributions are reduced across the
-      // wave with shuffles so that ONE lane issues ONE atomic per state word.
+      // Wave-uniform runs: when every pending lane of the wave hits the SAME slot
+      // (one group, a dominant key, or input clustered by key) 64 LDS atomics on
+      // one address would serialise (~1.8 cycles per lane measured).  Such rows
+      // are instead accumulated in lane-private registers keyed by the
+      // wave-uniform slot `acc.rslot`; the registers are folded into the LDS
+      // table only when the slot changes and at the end of the kernel.  Waves
+      // whose lanes disagree pay one ballot/readlane/ballot and fall through.
       s << "  bool pend = s >= 0;\n";
-      s << "#pragma unroll 1\n";
-      s << "  for (int round = 0; round < 4; ++round) {\n";
+      s << "  {\n";
       s << "    const u64 pm = __ballot(pend);\n";
-      s << "    if (pm == 0) break;\n";
-      s << "    const int leader = __ffsll((long long) pm) - 1;\n";
-      s << "    const int s0 = __shfl(s, leader, 64);\n";
-      s << "    const bool mine = pend && s == s0;\n";
-      s << "    const u64 same = __ballot(mine);\n";
-      s << "    if (__popcll(same) < 12) break;\n";
-      if (kp.need_first_row) {
-        s << "    { const u64 v = evql_wave_reduce<EVQL_OP_MIN_U64>(mine ? row : 0xFFFFFFFFFFFFFFFFull);\n";
-        s << "      if ((int) (threadIdx.x & 63u) == leader) evql_atomic<EVQL_OP_MIN_U64>(&lds[1 * EVQL_LSTRIDE + s0], v); }\n";
+      s << "    if (pm != 0) {\n";
+      s << "      const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long) pm) - 1);\n";
+      s << "      const int s0 = __builtin_amdgcn_readlane(s, leader);\n";
+      s << "      if (__ballot(pend && s == s0) == pm) {\n";
+      s << "        if (acc.rslot != s0) { evql_flush_private(lds, acc); acc.rslot = s0; }\n";
+      s << "        if (pend) {\n";
+      if (kp.need_first_row) s << "          acc.rfirst = row < acc.rfirst ? row : acc.rfirst;\n";
+      for (size_t i = 0; i < upd.size(); ++i) {
+        const auto& u = upd[i];
+        s << "          if (" << u.cond << ") acc.rw[" << i << "] = evql_combine<" << op_name(u.op)
+          << ">(acc.rw[" << i << "], " << u.bits << ");\n";
       }
-      for (const auto& u : upd) {
-        s << "    { const u64 v = evql_wave_reduce<" << op_name(u.op) << ">((mine && " << u.cond
-          << ") ? " << u.bits << " : evql_op_identity<" << op_name(u.op) << ">());\n";
-        s << "      const bool anyc = __ballot(mine && " << u.cond << ") != 0;\n";
-        s << "      if ((int) (threadIdx.x & 63u) == leader && anyc) evql_atomic<" << op_name(u.op)
-          << ">(&lds[" << (SB + u.word) << " * EVQL_LSTRIDE + s0], v); }\n";
-      }
-      s << "    pend = pend && !mine;\n";
-      s << "  }\n";
+      s << "        }\n";
+      s << "        pend = false;\n";
+      s << "      }\n    }\n  }\n";
       s << "  if (pend) {\n";
       emit_updates("lds", "EVQL_LSTRIDE", "s", "    ");
       s << "  }\n";
@@ -425,6 +468,12 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "  u64* lds = nullptr;\n";
   }
   s << "  EvqlAcc acc;\n  acc.passed = 0;\n  acc.spilled = 0;\n";
+  if (grouped && S > 0) {
+    s << "  acc.rslot = -1;\n  acc.rfirst = 0xFFFFFFFFFFFFFFFFull;\n";
+    for (size_t i = 0; i < updw.size(); ++i) {
+      s << "  acc.rw[" << i << "] = evql_op_identity<" << op_name(updw[i].op) << ">();\n";
+    }
+  }
   if (!grouped) {
     for (int w = 0; w < NW; ++w) {
       s << "  acc.w[" << w << "] = evql_op_identity<" << op_name(kp.states[w].op) << ">();\n";
@@ -517,6 +566,7 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     }
     s << "    }\n  }\n";
   } else if (S > 0) {
+    s << "  evql_flush_private(lds, acc);\n";
     s << "  __syncthreads();\n";
     s << "  for (u32 s = tid; s < EVQL_LSTRIDE; s += EVQL_BLOCK) {\n";
     s << "    const u64 k = lds[s];\n    if (k == EVQL_EMPTY) continue;\n";
