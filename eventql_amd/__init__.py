@@ -95,6 +95,7 @@ def lib():
     L.evql_query_partial_view.argtypes = [C.c_void_p, C.POINTER(K.PartialView)]
     L.evql_query_export_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
     L.evql_query_import_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.evql_query_reset.argtypes = [C.c_void_p]
     L.evql_set_kernel_cache_dir.argtypes = [C.c_char_p]
     L.evql_compile_only.argtypes = [C.POINTER(K.PlanDesc), C.POINTER(K.ColumnInfo), C.c_int,
                                     C.c_char_p, C.POINTER(C.c_size_t)]
@@ -340,6 +341,10 @@ class Query:
 
     def import_groups(self, device_ptr, n):
         _check(lib().evql_query_import_groups(self.h, device_ptr, n))
+
+    def reset(self):
+        """empty group table, no scan: merge target for import_groups"""
+        _check(lib().evql_query_reset(self.h))
 
     def close(self):
         if self.h:

@@ -14,6 +14,8 @@ Status table_from_image(evql_ctx* ctx, const void* image, size_t len, bool keep_
 Status query_prepare(evql_query* q);
 Status query_launch(evql_query* q);
 Status query_finish(evql_query* q);
+Status query_reset(evql_query* q);
+Status query_recount(evql_query* q);
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows);
 }  // namespace evql
 
@@ -578,11 +580,14 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
     if (!(status[0] & 2u)) break;
     return fail(EVQL_ENOMEM, "group table full during merge; raise groups_hint");
   }
-  // refresh the host copy of the result
-  q->launched = true;
-  hipEventRecord(q->ev0, s);
-  hipEventRecord(q->ev1, s);
-  return ret(query_finish(q));
+  // the host copy of the result (if any) is stale now
+  return ret(query_recount(q));
+  API_CATCH
+}
+
+int evql_query_reset(evql_query_t* q) {
+  API_TRY
+  return ret(query_reset(q));
   API_CATCH
 }
 

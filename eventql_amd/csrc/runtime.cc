@@ -834,9 +834,87 @@ Status query_finish(evql_query* q) {
     q->stats.rows_passed = counters[0];
     q->stats.used_lds_table = q->kp.lds_slots > 0;
     q->launched = false;
-    return fetch_results(q);
+    // the groups stay in HBM; they are compacted and copied to the host only
+    // when the first nextBatch asks for them (a partial aggregate that is merged
+    // on the device never leaves it).  Only the group count is read back.
+    {
+      uint64_t* d_cnt = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), 8));
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8,
+                                   uint32_t(q->kp.words_per_slot()), nullptr, 0, d_cnt,
+                                   ctx->stream));
+      uint64_t n = 0;
+      HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      hipFree(d_cnt);
+      q->ngroups = n;
+      q->stats.num_groups = n;
+    }
+    q->executed = true;
+    q->fetched = false;
+    q->emit_pos = 0;
+    return Status();
   }
   return Status::error(EVQL_ENOMEM, "group table kept overflowing");
+}
+
+// number of occupied slots after the table was changed behind the host's back
+// (import of another partition's groups)
+Status query_recount(evql_query* q) {
+  evql_ctx* ctx = q->ctx;
+  uint64_t* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), 8));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+  HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, uint32_t(q->kp.words_per_slot()),
+                               nullptr, 0, d_cnt, ctx->stream));
+  uint64_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  hipFree(d_cnt);
+  q->ngroups = n;
+  q->stats.num_groups = n;
+  q->fetched = false;
+  q->executed = true;
+  q->emit_pos = 0;
+  return Status();
+}
+
+// (re)creates an empty group table without scanning: the merge target of
+// GroupByMergeExpression (groupby.cc:528-637)
+Status query_reset(evql_query* q) {
+  evql_ctx* ctx = q->ctx;
+  const KernelPlan& kp = q->kp;
+  if (!q->d_gtab) {
+    uint64_t want = kp.key_mode == KEY_NONE ? 8 : std::max<uint64_t>(q->groups_hint * 4, 1 << 16);
+    uint64_t cap = 8;
+    while (cap < want) cap <<= 1;
+    Status st = alloc_gtab(q, cap);
+    if (!st.ok()) return st;
+  }
+  TableInitArgs ia{};
+  ia.words = q->d_gtab;
+  ia.stride = q->gcap + 8;
+  ia.nwords = uint32_t(kp.words_per_slot());
+  ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
+  int w = 1;
+  if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
+  HIP_TRY(launch_table_init(ia, ctx->stream));
+  HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, ctx->stream));
+  HIP_TRY(hipMemsetAsync(q->d_counters, 0, 64, ctx->stream));
+  HIP_TRY(hipEventRecord(q->ev0, ctx->stream));
+  HIP_TRY(hipEventRecord(q->ev1, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  q->ngroups = 0;
+  q->stats.num_groups = 0;
+  q->stats.rows_scanned = 0;
+  q->stats.rows_passed = 0;
+  q->executed = true;
+  q->fetched = false;
+  q->launched = false;
+  q->emit_pos = 0;
+  return Status();
 }
 
 static Status fetch_results(evql_query* q) {
@@ -934,6 +1012,7 @@ static Status fetch_results(evql_query* q) {
   q->stats.num_groups = n;
   q->emit_pos = 0;
   q->executed = true;
+  q->fetched = true;
   return Status();
 }
 
@@ -1025,6 +1104,10 @@ static void save_state(const AggPlan& a, const uint64_t* st, std::vector<uint8_t
 
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows) {
   if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
+  if (!q->fetched) {
+    Status st = fetch_results(q);
+    if (!st.ok()) return st;
+  }
   const KernelPlan& kp = q->kp;
   evql_table* t = q->table;
   const size_t nsel = q->select.size();

@@ -117,6 +117,7 @@ struct evql_query {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool launched = false;
   bool executed = false;
+  bool fetched = false;  // groups copied to the host (lazy, on first nextBatch)
   int grid = 0;
   // results
   std::vector<uint64_t> records;  // dense [kind, ident, (first_row), states...]

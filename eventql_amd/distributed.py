@@ -25,9 +25,19 @@ def partitions_for_rank(n_partitions, rank, world):
     return list(range(lo, min(lo + per, n_partitions)))
 
 
+def _staged_on_host(records, group):
+    """gloo moves host memory: device records are staged through the host (used
+    to rehearse the multi-rank path on a single GPU; RCCL needs one GPU per rank)"""
+    return records.device.type == "cuda" and dist.get_backend(group) == "gloo"
+
+
 def exchange_all_gather(records, n, record_words, max_groups, group=None):
     """records: int64 tensor holding >= n*record_words words (this rank's dense
     records).  Returns [(tensor_view, count)] for every rank, in rank order."""
+    if _staged_on_host(records, group):
+        parts = exchange_all_gather(records[:n * record_words].cpu(), n, record_words,
+                                    max_groups, group)
+        return [(t.to(records.device), c) for t, c in parts]
     world = dist.get_world_size(group)
     width = max_groups * record_words + 1
     send = torch.zeros(width, dtype=torch.int64, device=records.device)
@@ -65,6 +75,9 @@ def bucket_by_owner(records, n, record_words, world):
 def exchange_all_to_all(records, n, record_words, group=None):
     """hash-partitioned exchange: returns (tensor, count) of the records this rank
     owns, received from all ranks (its own included)"""
+    if _staged_on_host(records, group):
+        recv, cnt = exchange_all_to_all(records[:n * record_words].cpu(), n, record_words, group)
+        return recv.to(records.device), cnt
     world = dist.get_world_size(group)
     send, counts = bucket_by_owner(records, n, record_words, world)
     counts_cpu = counts.to("cpu")

@@ -420,6 +420,9 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst,
 int evql_query_import_groups(evql_query_t* q, const void* device_src,
                              uint64_t n_groups);
 uint32_t evql_query_record_words(const evql_query_t* q);
+/* empties the query's group table without scanning, so that it can serve as the
+ * merge target of partial aggregates (GroupByMergeExpression, groupby.cc:528-637) */
+int evql_query_reset(evql_query_t* q);
 
 /* ------------------------------------------------------------------------ */
 /* build support                                                              */
