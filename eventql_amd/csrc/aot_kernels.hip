@@ -19,10 +19,11 @@ __device__ __forceinline__ u64 rt_column_value(const u8* image, const RtColumn& 
 
 // ---- table maintenance -----------------------------------------------------------
 __global__ void k_table_init(TableInitArgs a) {
+  // slots of `nwords` adjacent words
   const u64 total = a.stride * a.nwords;
   for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (u64) gridDim.x * blockDim.x) {
-    a.words[i] = a.identity[i / a.stride];
+    a.words[i] = a.identity[i % a.nwords];
   }
 }
 
@@ -31,14 +32,14 @@ __global__ void k_table_compact(const u64* words, u64 gcap, u64 stride, u32 nwor
   const u64 nslots = gcap + 2;
   for (u64 s = (u64) blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
        s += (u64) gridDim.x * blockDim.x) {
-    const u64 k = words[s];
+    const u64 k = words[s * nwords];
     if (k == EVQL_EMPTY) continue;
     const u64 idx = atomicAdd(counter, 1ull);
     if (idx >= max_records) continue;
     u64* rec = out + idx * (nwords + 1);
     rec[0] = s == gcap ? 1ull : (s == gcap + 1 ? 2ull : 0ull);
     rec[1] = s == gcap ? EVQL_EMPTY : k;
-    for (u32 w = 1; w < nwords; ++w) rec[1 + w] = words[(u64) w * stride + s];
+    for (u32 w = 1; w < nwords; ++w) rec[1 + w] = words[s * nwords + w];
   }
 }
 
@@ -63,19 +64,19 @@ __global__ void k_table_merge(MergeArgs a, const u64* records, u64 n) {
     i64 gs;
     if (kind == 1) {
       gs = (i64) a.gcap;
-      a.words[gs] = 0;
+      a.words[(u64) gs * a.nwords] = 0;
     } else if (kind == 2) {
       gs = (i64) a.gcap + 1;
-      a.words[gs] = 0;
+      a.words[(u64) gs * a.nwords] = 0;
     } else {
-      gs = evql_gtab_find((u64*) a.words, a.gcap, ident, evql_mix64(ident));
+      gs = evql_gtab_find((u64*) a.words, a.nwords, a.gcap, ident, evql_mix64(ident));
     }
     if (gs < 0) {
       atomicOr(&a.status[0], EVQL_ST_TABLE_FULL);
       continue;
     }
     for (u32 w = 1; w < a.nwords; ++w) {
-      rt_atomic(a.ops[w], (u64*) &a.words[(u64) w * a.stride + gs], rec[1 + w]);
+      rt_atomic(a.ops[w], (u64*) &a.words[(u64) gs * a.nwords + w], rec[1 + w]);
     }
   }
 }

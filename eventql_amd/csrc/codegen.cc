@@ -198,7 +198,7 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   s << "#define EVQL_LSTRIDE " << (S + 2) << "\n";
   s << "#define EVQL_WORDS " << W << "\n";
   s << "#define EVQL_NSTATE " << NW << "\n";
-  s << "#define EVQL_GSTRIDE (A.gcap + 8)\n\n";
+  s << "\n";
 
   // update words of one row (count / sum / min / max state words), in order
   struct UpdWord {
@@ -376,15 +376,24 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   }
   s << "  }\n";
 
-  auto emit_updates = [&](const char* base, const char* stride, const char* slot,
-                          const char* indent) {
+  // address of word `w` of slot `slot`: LDS keeps word planes (bank spread),
+  // the HBM table keeps the words of a slot adjacent (one line per group)
+  auto word_at = [&](bool global, int w, const std::string& slot) {
+    char b[160];
+    if (global) {
+      snprintf(b, sizeof(b), "A.gtab[(u64) %s * EVQL_WORDS + %d]", slot.c_str(), w);
+    } else {
+      snprintf(b, sizeof(b), "lds[%d * EVQL_LSTRIDE + %s]", w, slot.c_str());
+    }
+    return std::string(b);
+  };
+  auto emit_updates = [&](bool global, const char* slot, const char* indent) {
     if (kp.need_first_row) {
-      s << indent << "evql_atomic<EVQL_OP_MIN_U64>(&" << base << "[1 * " << stride << " + "
-        << slot << "], row);\n";
+      s << indent << "evql_atomic<EVQL_OP_MIN_U64>(&" << word_at(global, 1, slot) << ", row);\n";
     }
     for (const auto& u : upd) {
-      s << indent << "if (" << u.cond << ") evql_atomic<" << op_name(u.op) << ">(&" << base << "["
-        << (SB + u.word) << " * " << stride << " + " << slot << "], " << u.bits << ");\n";
+      s << indent << "if (" << u.cond << ") evql_atomic<" << op_name(u.op) << ">(&"
+        << word_at(global, SB + u.word, slot) << ", " << u.bits << ");\n";
     }
   };
 
@@ -431,7 +440,7 @@ std::string generate_kernel_source(const KernelPlan& kp) {
       s << "        pend = false;\n";
       s << "      }\n    }\n  }\n";
       s << "  if (pend) {\n";
-      emit_updates("lds", "EVQL_LSTRIDE", "s", "    ");
+      emit_updates(false, "s", "    ");
       s << "  }\n";
       s << "  const bool spill = live && s < 0;\n";
       s << "  acc.spilled += spill ? 1 : 0;\n";
@@ -440,12 +449,12 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     }
     s << "  if (spill) {\n";
     s << "    i64 gs;\n";
-    s << "    if (knull) { gs = (i64) A.gcap + 1; A.gtab[gs] = 0; }\n";
-    s << "    else if (ident == EVQL_EMPTY) { gs = (i64) A.gcap; A.gtab[gs] = 0; }\n";
-    s << "    else gs = evql_gtab_find(A.gtab, A.gcap, ident, evql_mix64(ident));\n";
+    s << "    if (knull) { gs = (i64) A.gcap + 1; A.gtab[(u64) gs * EVQL_WORDS] = 0; }\n";
+    s << "    else if (ident == EVQL_EMPTY) { gs = (i64) A.gcap; A.gtab[(u64) gs * EVQL_WORDS] = 0; }\n";
+    s << "    else gs = evql_gtab_find(A.gtab, EVQL_WORDS, A.gcap, ident, evql_mix64(ident));\n";
     s << "    if (gs < 0) { atomicOr(&A.status[0], EVQL_ST_TABLE_FULL); }\n";
     s << "    else {\n";
-    emit_updates("A.gtab", "EVQL_GSTRIDE", "gs", "      ");
+    emit_updates(true, "gs", "      ");
     s << "    }\n  }\n";
   }
   s << "}\n\n";
@@ -562,7 +571,7 @@ std::string generate_kernel_source(const KernelPlan& kp) {
       s << "      { u64 v = red[" << w << "]; for (u32 k = 1; k < EVQL_BLOCK / 64; ++k) v = evql_combine<"
         << op_name(kp.states[w].op) << ">(v, red[k * " << (NW + 1) << " + " << w
         << "]); evql_atomic<" << op_name(kp.states[w].op) << ">(&A.gtab[" << (SB + w)
-        << " * EVQL_GSTRIDE], v); }\n";
+        << "], v); }\n";
     }
     s << "    }\n  }\n";
   } else if (S > 0) {
@@ -573,15 +582,15 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "    i64 gs;\n";
     s << "    if (s == EVQL_LDS_SLOTS) gs = (i64) A.gcap;\n";
     s << "    else if (s == EVQL_LDS_SLOTS + 1) gs = (i64) A.gcap + 1;\n";
-    s << "    else gs = evql_gtab_find(A.gtab, A.gcap, k, evql_mix64(k));\n";
+    s << "    else gs = evql_gtab_find(A.gtab, EVQL_WORDS, A.gcap, k, evql_mix64(k));\n";
     s << "    if (gs < 0) { atomicOr(&A.status[0], EVQL_ST_TABLE_FULL); continue; }\n";
-    s << "    if (s >= EVQL_LDS_SLOTS) A.gtab[gs] = 0;\n";
+    s << "    if (s >= EVQL_LDS_SLOTS) A.gtab[(u64) gs * EVQL_WORDS] = 0;\n";
     if (kp.need_first_row) {
-      s << "    evql_atomic<EVQL_OP_MIN_U64>(&A.gtab[1 * EVQL_GSTRIDE + gs], lds[1 * EVQL_LSTRIDE + s]);\n";
+      s << "    evql_atomic<EVQL_OP_MIN_U64>(&A.gtab[(u64) gs * EVQL_WORDS + 1], lds[1 * EVQL_LSTRIDE + s]);\n";
     }
     for (int w = 0; w < NW; ++w) {
-      s << "    evql_atomic<" << op_name(kp.states[w].op) << ">(&A.gtab[" << (SB + w)
-        << " * EVQL_GSTRIDE + gs], lds[" << (SB + w) << " * EVQL_LSTRIDE + s]);\n";
+      s << "    evql_atomic<" << op_name(kp.states[w].op) << ">(&A.gtab[(u64) gs * EVQL_WORDS + "
+        << (SB + w) << "], lds[" << (SB + w) << " * EVQL_LSTRIDE + s]);\n";
     }
     s << "  }\n";
   }

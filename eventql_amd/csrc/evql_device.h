@@ -48,7 +48,7 @@ struct EvqlArgs {
   u64 tile0;       // index of the first tile (absolute row / TILE_ROWS)
   const u8* row_filter;  // bit i == 0 drops row i; NULL = none
   u64 row_filter_len;
-  u64* gtab;       // global group table: word w of slot s at gtab[w*gcap + s]
+  u64* gtab;       // HBM group table: word w of slot s at gtab[s*W + w]
   u64 gcap;        // slots (power of two); two extra special slots follow
   u32* status;     // [0] error bits, [1] reserved
   u64* counters;   // [0] rows passed, [1] rows aggregated via LDS overflow
@@ -251,7 +251,10 @@ __device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32
 // global (HBM) table.  Keys never change once written, so a stale plain read
 // can only observe EMPTY, which the CAS then corrects.
 #define EVQL_GTAB_MAX_PROBE 128
-__device__ __forceinline__ i64 evql_gtab_find(u64* keys, u64 cap, u64 ident, u64 h) {
+// The HBM table is an array of slots of W consecutive words (identity first):
+// all words of a group share one 64-byte line / DRAM page, so the identity probe
+// and the state atomics of one row touch one line instead of W word planes.
+__device__ __forceinline__ i64 evql_gtab_find(u64* tab, u32 W, u64 cap, u64 ident, u64 h) {
   const u64 mask = cap - 1;
   u64 s = h & mask;
   // the host sizes the table for a load factor <= 1/4, where a chain of 128 is
@@ -260,10 +263,11 @@ __device__ __forceinline__ i64 evql_gtab_find(u64* keys, u64 cap, u64 ident, u64
   const u64 maxp = cap < EVQL_GTAB_MAX_PROBE ? cap : EVQL_GTAB_MAX_PROBE;
 #pragma unroll 1
   for (u64 probe = 0; probe < maxp; ++probe) {
-    u64 cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64* key = tab + s * W;
+    u64 cur = __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == ident) return (i64) s;
     if (cur == EVQL_EMPTY) {
-      u64 old = atomicCAS(&keys[s], EVQL_EMPTY, ident);
+      u64 old = atomicCAS(key, EVQL_EMPTY, ident);
       if (old == EVQL_EMPTY || old == ident) return (i64) s;
     }
     s = (s + 1) & mask;
