@@ -69,13 +69,15 @@ __global__ void k_table_merge(MergeArgs a, const u64* records, u64 n) {
       gs = (i64) a.gcap + 1;
       a.words[(u64) gs * a.nwords] = 0;
     } else {
-      gs = evql_gtab_find((u64*) a.words, a.nwords, a.gcap, ident, evql_mix64(ident));
+      gs = a.has_ident2
+               ? evql_gtab_find2((u64*) a.words, a.nwords, a.gcap, ident, rec[2], evql_mix64(ident))
+               : evql_gtab_find((u64*) a.words, a.nwords, a.gcap, ident, evql_mix64(ident));
     }
     if (gs < 0) {
       atomicOr(&a.status[0], EVQL_ST_TABLE_FULL);
       continue;
     }
-    for (u32 w = 1; w < a.nwords; ++w) {
+    for (u32 w = 1 + a.has_ident2; w < a.nwords; ++w) {
       rt_atomic(a.ops[w], (u64*) &a.words[(u64) gs * a.nwords + w], rec[1 + w]);
     }
   }

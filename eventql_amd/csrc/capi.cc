@@ -567,6 +567,8 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
     a.stride = q->gcap + 8;
     a.nwords = uint32_t(q->kp.words_per_slot());
     int w = 1;
+    a.has_ident2 = q->kp.has_ident2() ? 1 : 0;
+    if (q->kp.has_ident2()) a.ops[w++] = 255;
     if (q->kp.need_first_row) a.ops[w++] = 2;  // min
     for (const auto& sw : q->kp.states) a.ops[w++] = uint32_t(sw.op);
     a.status = q->d_status;

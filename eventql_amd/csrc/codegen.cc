@@ -239,7 +239,8 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "  if (acc.rslot >= 0) {\n";
     if (kp.need_first_row) {
       s << "    { const u64 v = evql_wave_reduce<EVQL_OP_MIN_U64>(acc.rfirst);\n";
-      s << "      if ((threadIdx.x & 63u) == 0) evql_atomic<EVQL_OP_MIN_U64>(&lds[1 * EVQL_LSTRIDE + acc.rslot], v); }\n";
+      s << "      if ((threadIdx.x & 63u) == 0) evql_atomic<EVQL_OP_MIN_U64>(&lds[" << kp.first_row_word()
+        << " * EVQL_LSTRIDE + acc.rslot], v); }\n";
       s << "    acc.rfirst = 0xFFFFFFFFFFFFFFFFull;\n";
     }
     for (size_t i = 0; i < updw.size(); ++i) {
@@ -302,7 +303,7 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     for (const auto& a : kp.aggs) n += size_t(a.nwords);
     return n;
   }();
-  s << "  u64 ident = 0; bool knull = false;\n";
+  s << "  u64 ident = 0; u64 ident2 = 0; bool knull = false;\n";
   for (size_t i = 0; i < nupd_words; ++i) {
     s << "  u64 ub" << i << " = 0; bool uc" << i << " = false;\n";
   }
@@ -315,14 +316,19 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "    ident = " << Emitter::as_bits(k) << ";\n";
     s << "    knull = (" << k.g << " & 1u) != 0;\n";
   } else if (kp.key_mode == KEY_HASHED) {
-    s << "    ident = 0x243f6a8885a308d3ull;\n";
+    s << "    ident = 0x243f6a8885a308d3ull; ident2 = 0x13198a2e03707344ull;\n";
     for (const auto& g : kp.group) {
       Val k = em.emit(g);
       s << em.o.str();
       em.o.str("");
       s << "    ident = evql_hash_combine(ident, " << Emitter::as_bits(k) << ");\n";
       s << "    ident = evql_hash_combine(ident, (u64) (" << k.g << " & 1u));\n";
+      s << "    ident2 = evql_mix64(ident2 * 0x9e3779b97f4a7c15ull + " << Emitter::as_bits(k)
+        << ") ^ (u64) (" << k.g << " & 1u);\n";
     }
+    // the all-ones pattern marks a free word
+    s << "    if (ident == EVQL_EMPTY) ident = EVQL_EMPTY - 1;\n";
+    s << "    if (ident2 == EVQL_EMPTY) ident2 = EVQL_EMPTY - 1;\n";
   }
   for (const auto& a : kp.aggs) {
     Val v{"0", "0u", EVQL_T_NIL};
@@ -389,7 +395,8 @@ std::string generate_kernel_source(const KernelPlan& kp) {
   };
   auto emit_updates = [&](bool global, const char* slot, const char* indent) {
     if (kp.need_first_row) {
-      s << indent << "evql_atomic<EVQL_OP_MIN_U64>(&" << word_at(global, 1, slot) << ", row);\n";
+      s << indent << "evql_atomic<EVQL_OP_MIN_U64>(&" << word_at(global, kp.first_row_word(), slot)
+        << ", row);\n";
     }
     for (const auto& u : upd) {
       s << indent << "if (" << u.cond << ") evql_atomic<" << op_name(u.op) << ">(&"
@@ -411,7 +418,12 @@ std::string generate_kernel_source(const KernelPlan& kp) {
       s << "  if (live && !bypass) {\n";
       s << "    if (knull) { s = EVQL_LDS_SLOTS + 1; lds[s] = 0; }\n";
       s << "    else if (ident == EVQL_EMPTY) { s = EVQL_LDS_SLOTS; lds[s] = 0; }\n";
-      s << "    else s = evql_lds_find<16>(lds, EVQL_LDS_SLOTS - 1, ident, (u32) evql_mix64(ident));\n";
+      if (kp.has_ident2()) {
+        s << "    else s = evql_lds_find2<16>(lds, lds + EVQL_LSTRIDE, EVQL_LDS_SLOTS - 1, ident, ident2, "
+             "(u32) evql_mix64(ident));\n";
+      } else {
+        s << "    else s = evql_lds_find<16>(lds, EVQL_LDS_SLOTS - 1, ident, (u32) evql_mix64(ident));\n";
+      }
       s << "    if (s < 0) atomicAdd(reinterpret_cast<u32*>(&lds[EVQL_WORDS * EVQL_LSTRIDE]), 1u);\n";
       s << "  }\n";
       // Wave-uniform runs: when every pending lane of the wave hits the SAME slot
@@ -451,7 +463,11 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "    i64 gs;\n";
     s << "    if (knull) { gs = (i64) A.gcap + 1; A.gtab[(u64) gs * EVQL_WORDS] = 0; }\n";
     s << "    else if (ident == EVQL_EMPTY) { gs = (i64) A.gcap; A.gtab[(u64) gs * EVQL_WORDS] = 0; }\n";
-    s << "    else gs = evql_gtab_find(A.gtab, EVQL_WORDS, A.gcap, ident, evql_mix64(ident));\n";
+    if (kp.has_ident2()) {
+      s << "    else gs = evql_gtab_find2(A.gtab, EVQL_WORDS, A.gcap, ident, ident2, evql_mix64(ident));\n";
+    } else {
+      s << "    else gs = evql_gtab_find(A.gtab, EVQL_WORDS, A.gcap, ident, evql_mix64(ident));\n";
+    }
     s << "    if (gs < 0) { atomicOr(&A.status[0], EVQL_ST_TABLE_FULL); }\n";
     s << "    else {\n";
     emit_updates(true, "gs", "      ");
@@ -467,7 +483,10 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "  if (tid == 0) lds[EVQL_WORDS * EVQL_LSTRIDE] = 0;  // rows that found no LDS slot\n";
     s << "  for (u32 i = tid; i < EVQL_LSTRIDE; i += EVQL_BLOCK) {\n";
     s << "    lds[i] = EVQL_EMPTY;\n";
-    if (kp.need_first_row) s << "    lds[1 * EVQL_LSTRIDE + i] = 0xFFFFFFFFFFFFFFFFull;\n";
+    if (kp.has_ident2()) s << "    lds[1 * EVQL_LSTRIDE + i] = EVQL_EMPTY;\n";
+    if (kp.need_first_row) {
+      s << "    lds[" << kp.first_row_word() << " * EVQL_LSTRIDE + i] = 0xFFFFFFFFFFFFFFFFull;\n";
+    }
     for (int w = 0; w < NW; ++w) {
       s << "    lds[" << (SB + w) << " * EVQL_LSTRIDE + i] = evql_op_identity<"
         << op_name(kp.states[w].op) << ">();\n";
@@ -582,11 +601,16 @@ std::string generate_kernel_source(const KernelPlan& kp) {
     s << "    i64 gs;\n";
     s << "    if (s == EVQL_LDS_SLOTS) gs = (i64) A.gcap;\n";
     s << "    else if (s == EVQL_LDS_SLOTS + 1) gs = (i64) A.gcap + 1;\n";
-    s << "    else gs = evql_gtab_find(A.gtab, EVQL_WORDS, A.gcap, k, evql_mix64(k));\n";
+    if (kp.has_ident2()) {
+      s << "    else gs = evql_gtab_find2(A.gtab, EVQL_WORDS, A.gcap, k, lds[EVQL_LSTRIDE + s], evql_mix64(k));\n";
+    } else {
+      s << "    else gs = evql_gtab_find(A.gtab, EVQL_WORDS, A.gcap, k, evql_mix64(k));\n";
+    }
     s << "    if (gs < 0) { atomicOr(&A.status[0], EVQL_ST_TABLE_FULL); continue; }\n";
     s << "    if (s >= EVQL_LDS_SLOTS) A.gtab[(u64) gs * EVQL_WORDS] = 0;\n";
     if (kp.need_first_row) {
-      s << "    evql_atomic<EVQL_OP_MIN_U64>(&A.gtab[(u64) gs * EVQL_WORDS + 1], lds[1 * EVQL_LSTRIDE + s]);\n";
+      s << "    evql_atomic<EVQL_OP_MIN_U64>(&A.gtab[(u64) gs * EVQL_WORDS + " << kp.first_row_word()
+        << "], lds[" << kp.first_row_word() << " * EVQL_LSTRIDE + s]);\n";
     }
     for (int w = 0; w < NW; ++w) {
       s << "    evql_atomic<" << op_name(kp.states[w].op) << ">(&A.gtab[(u64) gs * EVQL_WORDS + "

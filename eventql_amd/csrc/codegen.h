@@ -50,9 +50,14 @@ struct KernelPlan {
   KeyMode key_mode = KEY_NONE;
   bool need_first_row = false;
   bool has_row_filter = false;
-  // slot layout: word 0 identity, [word 1 first_row], then states
-  int words_per_slot() const { return 1 + (need_first_row ? 1 : 0) + int(states.size()); }
-  int state_word_base() const { return 1 + (need_first_row ? 1 : 0); }
+  // slot layout: word 0 identity, [second identity word], [first_row], states.
+  // Hashed keys (several keys / strings) are identified by TWO independent
+  // 64-bit hashes of the key tuple -- like the reference, which identifies a
+  // group by a hash of its tuple bytes (SHA1, groupby.cc:129-135).
+  bool has_ident2() const { return key_mode == KEY_HASHED; }
+  int first_row_word() const { return 1 + (has_ident2() ? 1 : 0); }
+  int words_per_slot() const { return state_word_base() + int(states.size()); }
+  int state_word_base() const { return first_row_word() + (need_first_row ? 1 : 0); }
   // launch shape
   int block = 256;
   int unroll = 4;

@@ -275,6 +275,49 @@ __device__ __forceinline__ i64 evql_gtab_find(u64* tab, u32 W, u64 cap, u64 iden
   return -1;
 }
 
+// ---- 128-bit identities (hashed keys): word 0 and word 1 are both claimed with
+// a CAS.  Two different keys that agree in the first hash race for the second
+// word of the slot; the loser sees a foreign value there and simply moves on
+// along the chain, so every (h1, h2) pair ends up owning exactly one slot
+// without any lock.
+template <int MAXP>
+__device__ __forceinline__ int evql_lds_find2(u64* keys, u64* keys2, u32 mask, u64 ident,
+                                              u64 ident2, u32 h) {
+  u32 s = (u32) ident & mask;
+#pragma unroll 1
+  for (int probe = 0; probe <= MAXP; ++probe) {
+    u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);
+    if (cur == EVQL_EMPTY) cur = atomicCAS(&keys[s], EVQL_EMPTY, ident);
+    if (cur == EVQL_EMPTY || cur == ident) {
+      u64 c2 = *reinterpret_cast<volatile u64*>(&keys2[s]);
+      if (c2 == EVQL_EMPTY) c2 = atomicCAS(&keys2[s], EVQL_EMPTY, ident2);
+      if (c2 == EVQL_EMPTY || c2 == ident2) return (int) s;
+    }
+    s = probe == 0 ? (h & mask) : ((s + 1) & mask);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ i64 evql_gtab_find2(u64* tab, u32 W, u64 cap, u64 ident, u64 ident2,
+                                               u64 h) {
+  const u64 mask = cap - 1;
+  u64 s = h & mask;
+  const u64 maxp = cap < EVQL_GTAB_MAX_PROBE ? cap : EVQL_GTAB_MAX_PROBE;
+#pragma unroll 1
+  for (u64 probe = 0; probe < maxp; ++probe) {
+    u64* key = tab + s * W;
+    u64 cur = __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == EVQL_EMPTY) cur = atomicCAS(key, EVQL_EMPTY, ident);
+    if (cur == EVQL_EMPTY || cur == ident) {
+      u64 c2 = __hip_atomic_load(key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c2 == EVQL_EMPTY) c2 = atomicCAS(key + 1, EVQL_EMPTY, ident2);
+      if (c2 == EVQL_EMPTY || c2 == ident2) return (i64) s;
+    }
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
 // 64-bit wave shuffle
 __device__ __forceinline__ u64 evql_shfl_xor(u64 v, int m) {
   u32 lo = (u32) v, hi = (u32) (v >> 32);

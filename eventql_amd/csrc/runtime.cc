@@ -758,6 +758,7 @@ Status query_launch(evql_query* q) {
   ia.nwords = uint32_t(kp.words_per_slot());
   ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
   int w = 1;
+  if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
   if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
   for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
   HIP_TRY(launch_table_init(ia, s));
@@ -898,6 +899,7 @@ Status query_reset(evql_query* q) {
   ia.nwords = uint32_t(kp.words_per_slot());
   ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
   int w = 1;
+  if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
   if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
   for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
   HIP_TRY(launch_table_init(ia, ctx->stream));
@@ -951,7 +953,7 @@ static Status fetch_results(evql_query* q) {
     const size_t rw = nwords + 1;
     std::vector<uint64_t> idx(n);
     for (uint64_t i = 0; i < n; ++i) idx[i] = i;
-    const size_t keyw = kp.need_first_row ? 2 : 1;
+    const size_t keyw = kp.need_first_row ? size_t(1 + kp.first_row_word()) : 1;
     const uint64_t* r = q->records.data();
     std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
       const uint64_t ka = r[a * rw + keyw], kb = r[b * rw + keyw];
@@ -971,7 +973,7 @@ static Status fetch_results(evql_query* q) {
     const uint32_t nc = uint32_t(kp.cols.size());
     std::vector<uint64_t> rows(n);
     const size_t rw = nwords + 1;
-    for (uint64_t i = 0; i < n; ++i) rows[i] = q->records[i * rw + 2];
+    for (uint64_t i = 0; i < n; ++i) rows[i] = q->records[i * rw + 1 + kp.first_row_word()];
     std::vector<RtColumn> rc(nc);
     for (uint32_t c = 0; c < nc; ++c) {
       const ColAccess& ca = kp.cols[c];
@@ -1124,7 +1126,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
     const uint64_t* st = rec + 1 + kp.state_word_base();
     bool have_inputs = false;
     if (kp.need_first_row) {
-      const uint64_t row = rec[2];
+      const uint64_t row = rec[1 + kp.first_row_word()];
       for (uint32_t c = 0; c < nc; ++c) {
         const ColAccess& ca = kp.cols[c];
         Value v;
