@@ -325,6 +325,24 @@ __global__ void __launch_bounds__(kBlock) k_synth(const SynthArgs* ap, u64 nchun
   }
 }
 
+// ---- partitioned aggregation: per-bucket prefix over workgroups ---------------------
+// counts[b][w] (tuples of workgroup w in bucket b) -> exclusive prefix inside the
+// bucket, totals[b] = size of bucket b
+__global__ void __launch_bounds__(kBlock) k_part_scan(u32* counts, u64 nwg, u64* totals) {
+  const u64 b = blockIdx.x;
+  u32 carry = 0;
+  for (u64 base = 0; base < nwg; base += kBlock) {
+    const u64 w = base + threadIdx.x;
+    const u32 v = w < nwg ? counts[b * nwg + w] : 0;
+    u32 total;
+    const u32 ex = block_excl_scan(v, &total);
+    if (w < nwg) counts[b * nwg + w] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[b] = carry;
+}
+
 // ---- nested (Dremel) scans ---------------------------------------------------------
 // level stream (bit-packed, width `bits`) -> one byte per slot, plus per-tile
 // counts of slots with level <= thr[c] for up to 4 thresholds (thr = 255 => skip)
@@ -531,6 +549,13 @@ hipError_t launch_string_hash(const uint8_t* image, const uint64_t* pages,
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_string_hash, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
                      (const u64*) pages, (const u64*) offsets, lens, (u64) n, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_part_scan(uint32_t* counts, uint64_t npart, uint64_t nwg, uint64_t* totals,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_part_scan, dim3((unsigned) npart), dim3(kBlock), 0, s, counts, (u64) nwg,
+                     (u64*) totals);
   return hipGetLastError();
 }
 

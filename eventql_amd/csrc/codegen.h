@@ -62,6 +62,10 @@ struct KernelPlan {
   int block = 256;
   int unroll = 4;
   int lds_slots = 0;  // 0 => aggregate straight into the HBM table
+  // high cardinality: radix-partition the passing rows into 2^part_bits buckets
+  // of tuples, then aggregate each bucket in LDS (codegen_kernels.inc)
+  bool partitioned = false;
+  int part_bits = 12;
   int tile_rows() const { return block * 2 * unroll; }
 };
 

@@ -61,6 +61,21 @@ bool strings_only_bare(const ExprPtr& e) {
   return true;
 }
 
+// can the value carry STAG_NULL?  (pure functions always produce tag 0)
+bool expr_may_be_null(const ExprPtr& e, const std::vector<ColAccess>& cols) {
+  if (!e) return false;
+  switch (e->kind) {
+    case Expr::INPUT:
+      return e->input < cols.size() && cols[e->input].has_tags;
+    case Expr::LITERAL:
+      return (e->lit_tag & 1) != 0;
+    case Expr::IF:
+      return expr_may_be_null(e->args[1], cols) || expr_may_be_null(e->args[2], cols);
+    default:
+      return false;
+  }
+}
+
 int op_for_minmax(uint32_t fn) {
   switch (fn) {
     case EVQL_AGG_MIN_UINT64: return 2;
@@ -311,6 +326,8 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     }
   }
   if (int(kp.states.size()) > kMaxStateWords) return unsup("too many aggregate state words");
+  q->n_update_words = 0;
+  for (const auto& a : kp.aggs) q->n_update_words += a.nwords;
   // PartialGroupBy rows carry SHA1(tuple bytes): with a hashed identity the key
   // values have to be re-read from the group's first row
   if (plan->group_mode == EVQL_MODE_PARTIAL && kp.key_mode == KEY_HASHED) {
@@ -336,8 +353,20 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     // works (4000 dense groups in 4096 slots: 0.63 ms vs 24 ms HBM-only for 2e8
     // rows); a workgroup whose table does thrash switches itself to the HBM
     // table (`bypass`).  Only far beyond the LDS capacity is the table skipped.
-    if (hint > 8 * smax) {
-      kp.lds_slots = 0;  // high cardinality: aggregate straight into the HBM table
+    const char* fp = getenv("EVQL_FORCE_PARTITIONED");
+    const bool part_ok = !(kp.key_mode == KEY_EXACT && expr_may_be_null(kp.group[0], kp.cols));
+    if ((hint > 8 * smax || (fp && atoi(fp) == 1)) && part_ok && !(fp && atoi(fp) == 0)) {
+      // high cardinality: one random HBM atomic per state word per row tops out at
+      // the chip's scattered-atomic rate (~2e10/s measured).  Instead the passing
+      // rows are radix-partitioned into buckets small enough for the LDS table
+      // (streaming traffic) and every bucket is aggregated in LDS.
+      kp.partitioned = true;
+      kp.lds_slots = int(smax);
+      kp.block = 1024;
+      kp.part_bits = 8;
+      while (kp.part_bits < 14 && (hint >> kp.part_bits) > smax / 2) ++kp.part_bits;
+    } else if (hint > 8 * smax) {
+      kp.lds_slots = 0;  // (nullable exact key) aggregate straight into the HBM table
       kp.block = 256;
     } else {
       uint64_t s = smax;

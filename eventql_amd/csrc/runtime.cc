@@ -104,6 +104,11 @@ Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out, boo
   if (load_module) {
     HIP_TRY(hipModuleLoadData(&out->mod, code.data()));
     HIP_TRY(hipModuleGetFunction(&out->fn, out->mod, "evql_scan_agg"));
+    if (source.find("evql_part_aggregate") != std::string::npos) {
+      HIP_TRY(hipModuleGetFunction(&out->fn_count, out->mod, "evql_part_count"));
+      HIP_TRY(hipModuleGetFunction(&out->fn_scatter, out->mod, "evql_part_scatter"));
+      HIP_TRY(hipModuleGetFunction(&out->fn_aggregate, out->mod, "evql_part_aggregate"));
+    }
     if (ctx) ctx->modules[key] = *out;
   }
   return Status();
@@ -218,6 +223,9 @@ evql_query::~evql_query() {
   if (d_status) hipFree(d_status);
   if (d_counters) hipFree(d_counters);
   if (d_row_filter) hipFree(d_row_filter);
+  if (d_part_counts) hipFree(d_part_counts);
+  if (d_bucket_start) hipFree(d_bucket_start);
+  if (d_tuples) hipFree(d_tuples);
   for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
@@ -790,6 +798,56 @@ Status query_launch(evql_query* q) {
       a.col[i].soa = m.d_values;
       a.col[i].tags = m.d_tags;
     }
+  }
+  if (kp.partitioned && a.ntiles > 0) {
+    // count -> per-bucket prefix -> scatter -> per-bucket LDS aggregation
+    const uint64_t npart = 1ull << kp.part_bits;
+    const uint64_t nwg = std::min<uint64_t>(uint64_t(q->grid), a.ntiles);
+    HostArgsWithPart ap{};
+    ap.a = a;
+    ap.p.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
+    ap.p.nwg = nwg;
+    if (!q->d_part_counts) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_part_counts),
+                        npart * uint64_t(q->grid) * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_bucket_start), (npart + 2) * 8));
+    }
+    ap.p.counts = q->d_part_counts;
+    ap.p.bucket_start = q->d_bucket_start;
+    ap.p.tuples = q->d_tuples;
+    size_t psz = sizeof(HostArgsWithPart);
+    void* pconfig[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ap, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz,
+                       HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipEventRecord(q->ev0, s));
+    HIP_TRY(hipModuleLaunchKernel(q->module.fn_count, unsigned(nwg), 1, 1, kp.block, 1, 1, 0, s,
+                                  nullptr, pconfig));
+    HIP_TRY(hipMemsetAsync(q->d_bucket_start, 0, (npart + 2) * 8, s));
+    HIP_TRY(launch_part_scan(q->d_part_counts, npart, nwg, q->d_bucket_start, s));
+    uint64_t* d_total = q->d_bucket_start + npart + 1;
+    HIP_TRY(launch_exclusive_scan(q->d_bucket_start, npart + 1, d_total, s));
+    uint64_t ntuples = 0;
+    HIP_TRY(hipMemcpyAsync(&ntuples, d_total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ntuples > q->tuples_cap) {
+      if (q->d_tuples) hipFree(q->d_tuples);
+      q->d_tuples = nullptr;
+      const uint64_t cap = ntuples + ntuples / 16 + 1024;
+      const uint64_t tw = uint64_t(kp.first_row_word() + (kp.need_first_row ? 1 : 0)) +
+                          uint64_t(q->n_update_words);
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_tuples), cap * tw * 8));
+      q->tuples_cap = cap;
+    }
+    ap.p.tuples = q->d_tuples;
+    HIP_TRY(hipModuleLaunchKernel(q->module.fn_scatter, unsigned(nwg), 1, 1, kp.block, 1, 1, 0, s,
+                                  nullptr, pconfig));
+    const unsigned agrid = unsigned(std::min<uint64_t>(npart, uint64_t(q->grid)));
+    HIP_TRY(hipModuleLaunchKernel(q->module.fn_aggregate, agrid, 1, 1, kp.block, 1, 1, 0, s, nullptr,
+                                  pconfig));
+    HIP_TRY(hipEventRecord(q->ev1, s));
+    q->launched = true;
+    q->stats.n_kernel_launches = 6;
+    q->stats.rows_scanned = a.row_end - a.row_begin;
+    return Status();
   }
   size_t sz = sizeof(HostArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,

@@ -49,7 +49,22 @@ struct Status {
 struct Module {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
+  // partitioned high-cardinality path (present only when the plan asks for it)
+  hipFunction_t fn_count = nullptr, fn_scatter = nullptr, fn_aggregate = nullptr;
   size_t code_size = 0;
+};
+
+// host mirror of the generated EvqlPartArgs
+struct HostPartArgs {
+  uint64_t tiles_per_wg;
+  uint32_t* counts;
+  const uint64_t* bucket_start;
+  uint64_t* tuples;
+  uint64_t nwg;
+};
+struct HostArgsWithPart {
+  HostArgs a;
+  HostPartArgs p;
 };
 
 }  // namespace evql
@@ -102,6 +117,12 @@ struct evql_query {
   std::vector<uint8_t> row_filter_host;
   uint64_t row_filter_len = 0;
   uint8_t* d_row_filter = nullptr;
+  // partitioned path buffers
+  uint32_t* d_part_counts = nullptr;
+  uint64_t* d_bucket_start = nullptr;
+  uint64_t* d_tuples = nullptr;
+  uint64_t tuples_cap = 0;  // in tuples
+  int n_update_words = 0;   // update words per row (tuple payload)
   // nested (Dremel) scans: flattened per-row SoA columns, one per scan column
   bool nested = false;
   uint64_t nested_rows = 0;

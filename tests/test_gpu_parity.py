@@ -81,6 +81,37 @@ def test_high_cardinality(mixed):
           group_by=[col("b")], groups_hint=70000)
 
 
+def test_partitioned_high_cardinality_path(mixed, monkeypatch):
+    """radix-partition + per-bucket LDS aggregation (count / scatter / aggregate
+    kernels), forced on for small group counts too"""
+    t, img, c = mixed
+    monkeypatch.setenv("EVQL_FORCE_PARTITIONED", "1")
+    for kw in (
+        dict(select=[col("w"), count(1), sum_(col("a")), sum_(col("v"))], group_by=[col("w")]),
+        dict(select=[col("k"), count(1), sum_(col("a")), min_(col("v")), max_(col("b")),
+                     mean(col("n")), min_(col("nv"))], group_by=[col("k")], where=W),
+        # first-row semantics and hashed (multi-column / string) identities
+        dict(select=[col("k"), col("a"), col("s"), count(1)], group_by=[col("k")]),
+        dict(select=[col("k"), col("f"), count(1), sum_(col("p"))], group_by=[col("k"), col("f")],
+             key_cols=2),
+        dict(select=[col("s"), count(1), max_(col("a"))], group_by=[col("s")]),
+        dict(select=[col("b"), count(1), sum_(col("v"))], group_by=[col("b")], row_end=123_457),
+    ):
+        kc = kw.pop("key_cols", 1)
+        q_src = None
+        got, exp, st = check(t, img, key_cols=kc, groups_hint=300_000, **kw)
+    # the kernels really are the partitioned ones
+    plan = Plan(T.MIXED_SCHEMA, select=[col("w"), count(1)], group_by=[col("w")],
+                groups_hint=300_000)
+    q = t.query(plan)
+    assert "evql_part_scatter" in q.kernel_source()
+    q.close()
+    monkeypatch.setenv("EVQL_FORCE_PARTITIONED", "0")
+    q = t.query(plan)
+    assert "evql_part_scatter" not in q.kernel_source()
+    q.close()
+
+
 def test_global_aggregates(mixed):
     t, img, _ = mixed
     check(t, img, key_cols=0, select=[count(1)])
