@@ -17,6 +17,8 @@ __device__ __forceinline__ u64 rt_column_value(const u8* image, const RtColumn& 
   }
 }
 
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total);
+
 // ---- table maintenance -----------------------------------------------------------
 __global__ void k_table_init(TableInitArgs a) {
   // slots of `nwords` adjacent words
@@ -29,13 +31,22 @@ __global__ void k_table_init(TableInitArgs a) {
 
 __global__ void k_table_compact(const u64* words, u64 gcap, u64 stride, u32 nwords,
                                 u64* out, u64 max_records, u64* counter) {
+  // one atomic per workgroup and round (not per occupied slot: with 1e7 groups a
+  // per-slot counter serialised 12 ms of same-address atomics)
+  __shared__ u64 base_s;
   const u64 nslots = gcap + 2;
-  for (u64 s = (u64) blockIdx.x * blockDim.x + threadIdx.x; s < nslots;
-       s += (u64) gridDim.x * blockDim.x) {
-    const u64 k = words[s * nwords];
-    if (k == EVQL_EMPTY) continue;
-    const u64 idx = atomicAdd(counter, 1ull);
-    if (idx >= max_records) continue;
+  const u64 rounds = (nslots + (u64) gridDim.x * blockDim.x - 1) / ((u64) gridDim.x * blockDim.x);
+  for (u64 it = 0; it < rounds; ++it) {
+    const u64 s = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const u64 k = s < nslots ? words[s * nwords] : EVQL_EMPTY;
+    const bool occ = k != EVQL_EMPTY;
+    u32 total;
+    const u32 ex = block_excl_scan(occ ? 1u : 0u, &total);
+    if (threadIdx.x == 0) base_s = total ? atomicAdd(counter, (u64) total) : 0;
+    __syncthreads();
+    const u64 idx = base_s + ex;
+    __syncthreads();
+    if (!occ || idx >= max_records) continue;
     u64* rec = out + idx * (nwords + 1);
     rec[0] = s == gcap ? 1ull : (s == gcap + 1 ? 2ull : 0ull);
     rec[1] = s == gcap ? EVQL_EMPTY : k;
