@@ -37,7 +37,19 @@ QUERIES = {
     "config2": ("k, sum(v), count(1) GROUP BY k", "kv", 2),
     "config3": ("k, sum(v), count(1), sum(b) WHERE a>30000 AND b<30000 GROUP BY k", "kabv", 4),
     "config4": ("u, sum(a), count(1), sum(v) GROUP BY u  (u uniform in [0,1e7))", "uav", 3),
+    # nested: REPEATED RECORD items{position, price}, Dremel flattening (CSTableScan)
+    "config5": ("items.position, count(1), sum(items.price) GROUP BY items.position "
+                "(REPEATED RECORD items, rlevel 1 / dlevel 2)", None, 2),
 }
+
+
+def config5_plan():
+    from eventql_amd import capi as K
+    from eventql_amd.plan import Plan, col, count, sum_
+    S = {"id": K.T_UINT64, "items.position": K.T_UINT64, "items.price": K.T_UINT64,
+         "score": K.T_FLOAT64}
+    return Plan(S, select=[col("items.position"), count(1), sum_(col("items.price"))],
+                group_by=[col("items.position")], scan_mode=K.SCAN_NESTED, groups_hint=16)
 
 
 def cpu_baseline(ctx, plan_fn, columns, sample_rows, **gen_kw):
@@ -100,15 +112,23 @@ def main():
     query_text, columns, ncols = QUERIES[args.workload]
     high_card = args.workload == "config4"
     n_keys = 10_000_000
-    rows = args.rows or (125_000_000 if high_card else 1_000_000_000)
-    plan_fn = {"config2": B.config2, "config3": B.config3,
+    nested = args.workload == "config5"
+    rows = args.rows or (125_000_000 if high_card else (20_000_000 if nested else 1_000_000_000))
+    plan_fn = {"config2": B.config2, "config3": B.config3, "config5": config5_plan,
                "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw)}[args.workload]
     gen_kw = dict(u_mod=n_keys) if high_card else {}
 
     ctx = E.Context(device)
     # every rank owns one partition; different seeds => different partitions
     seed = synth.SEED if rank == 0 else (synth.SEED + 0x9E3779B97F4A7C15 * rank) & synth.MASK
-    table = ctx.generate(rows, columns, seed=seed, **gen_kw)
+    nested_image = None
+    if nested:
+        # `rows` = records; written by the host writer (levels + LEB128 / bit-packed
+        # data), then resident in HBM like any other table
+        nested_image, nested_stats = synth.items_table_image(rows, seed=3 + rank)
+        table = ctx.open_image(nested_image)
+    else:
+        table = ctx.generate(rows, columns, seed=seed, **gen_kw)
     ctx.synchronize()
     q = table.query(plan_fn())
     rw = q.record_words()
@@ -232,8 +252,25 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample_rows or (4_000_000 if high_card else 40_000_000)
-            out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
+            if nested:
+                import oracle_lib as O
+                n_s = min(rows, args.cpu_sample_rows or 2_000_000)
+                img_s, _ = synth.items_table_image(n_s, seed=3)
+                t0c = time.time()
+                res = O.oracle_run(img_s, plan_fn())
+                dtc = time.time() - t0c
+                out["cpu_baseline"] = dict(
+                    value=n_s / dtc, unit="records/s", cores=1, kind="port",
+                    sample="%d-record instance, oracle (C restatement of CSTableScan "
+                           "NO_AGGREGATION + GroupBy), %d groups, %.1f s" % (n_s, res.nrows, dtc))
+            else:
+                sample = args.cpu_sample_rows or (4_000_000 if high_card else 40_000_000)
+                out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
+        if nested:
+            out["config"]["records_per_gpu"] = rows
+            out["config"]["flattened_rows_per_gpu"] = int(stats["rows_scanned"])
+            out["config"]["encodings"] = "levels bit-packed, position UINT32_BITPACKED(4b), price LEB128"
+            out["unit"] = "records/s"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -58,38 +58,6 @@ ITEMS_SCHEMA = {"id": K.T_UINT64, "items.position": K.T_UINT64, "items.price": K
 
 @functools.lru_cache(maxsize=2)
 def items_table(nrec=100_000, seed=3):
-    """config-5 shape: REPEATED RECORD items{position, price} (rlevel_max 1,
-    dlevel_max 2), geometric 0..8 items per record, plus two top-level columns"""
-    rng = np.random.default_rng(seed)
-    cnt = np.minimum(rng.geometric(0.35, nrec) - 1, 8)
-    # slots: a record with no items still has one (r=0, d=0) slot
-    slots = np.maximum(cnt, 1)
-    total = int(slots.sum())
-    starts = np.concatenate([[0], np.cumsum(slots)[:-1]])
-    rl = np.ones(total, np.uint64)
-    rl[starts] = 0
-    rec_of_slot = np.repeat(np.arange(nrec), slots)
-    dl = np.where(cnt[rec_of_slot] > 0, 2, 0).astype(np.uint64)
-    pos = (np.arange(total) - starts[rec_of_slot] + 1).astype(np.uint64)
-    price = rng.integers(1, 100000, total).astype(np.uint64)
-    ids = np.arange(nrec, dtype=np.uint64) * np.uint64(7)
-    score = rng.random(nrec) * 100.0
-    w = E.Writer([
-        dict(name="id", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
-        dict(name="items.position", logical_type=K.COL_UNSIGNED_INT,
-             storage_type=K.ENC_UINT32_BITPACKED, rlevel_max=1, dlevel_max=2,
-             bitpack_max_value=15),
-        dict(name="items.price", logical_type=K.COL_UNSIGNED_INT,
-             storage_type=K.ENC_UINT64_LEB128, rlevel_max=1, dlevel_max=2),
-        dict(name="score", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754,
-             dlevel_max=1)])
-    w.put("id", ids)
-    w.put("items.position", pos, rlvl=rl, dlvl=dl)
-    w.put("items.price", price, rlvl=rl, dlvl=dl)
-    w.put("score", score, present=(np.arange(nrec) % 9 != 0).astype(np.uint8))
-    w.commit(nrec)
-    img = w.image()
-    w.close()
-    defined = dl == 2
-    return img, dict(cnt=cnt, total=total, n_items=int(defined.sum()),
-                     sum_price=int(price[defined].sum()), sum_pos=int(pos[defined].sum()))
+    """config-5 shape, see eventql_amd.synth.items_table_image"""
+    from eventql_amd import synth
+    return synth.items_table_image(nrec, seed)
