@@ -98,7 +98,7 @@ def mixed_table(n=300_000):
     return img, c
 
 
-def compare_results(got_rows, exp_rows, types, key_cols=1, rel=1e-6):
+def compare_results(got_rows, exp_rows, types, key_cols=1, rel=1e-6, abs_tol=0.0):
     """order-insensitive comparison: integers / strings / NULLs bit-exact, floats
     within `rel` relative (BASELINE.json north_star: 1e-6)"""
     g = {tuple(r[:key_cols]): r for r in got_rows}
@@ -112,6 +112,9 @@ def compare_results(got_rows, exp_rows, types, key_cols=1, rel=1e-6):
                 if b != b:  # NaN
                     assert a != a, (k, gr, er)
                 else:
-                    assert abs(a - b) <= rel * max(abs(b), 1e-300), (k, ci, gr, er)
+                    if b in (float("inf"), float("-inf")):
+                        assert a == b, (k, ci, gr, er)
+                    else:
+                        assert abs(a - b) <= rel * max(abs(b), 1e-300) + abs_tol, (k, ci, gr, er)
             else:
                 assert a == b, (k, ci, gr, er)
