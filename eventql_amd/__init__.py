@@ -75,6 +75,7 @@ def lib():
     L.evql_writer_commit.argtypes = [C.c_void_p, C.c_uint64]
     L.evql_writer_image.restype = C.c_void_p
     L.evql_writer_image.argtypes = [C.c_void_p, _u64p]
+    L.evql_cstable_upgrade.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
     L.evql_writer_write_file.argtypes = [C.c_void_p, C.c_char_p]
     L.evql_writer_destroy.argtypes = [C.c_void_p]
     L.evql_query_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(K.PlanDesc),
@@ -111,6 +112,18 @@ def _check(rc):
 
 def _ptr(a, ty):
     return a.ctypes.data_as(ty) if a is not None else None
+
+
+def upgrade_image(image):
+    """cstable v0.1.0 image -> v0.2.0 image (evql_cstable_upgrade; host-only)"""
+    buf = bytes(image)
+    n = C.c_uint64()
+    rc = lib().evql_cstable_upgrade(buf, len(buf), None, 0, C.byref(n))
+    if rc != K.EVQL_EARG or n.value == 0:
+        _check(rc)
+    out = C.create_string_buffer(n.value)
+    _check(lib().evql_cstable_upgrade(buf, len(buf), out, n.value, C.byref(n)))
+    return out.raw[:n.value]
 
 
 # ---------------------------------------------------------------------------

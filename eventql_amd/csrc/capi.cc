@@ -425,6 +425,18 @@ const void* evql_writer_image(const evql_writer_t* w, uint64_t* len) {
   return w->w->image().data();
 }
 
+int evql_cstable_upgrade(const void* image, uint64_t len, void* dst, uint64_t dst_cap,
+                         uint64_t* out_len) {
+  if (!image || !out_len) return fail(EVQL_EARG, "null argument");
+  std::vector<uint8_t> v2;
+  std::string e = transcode_v1_to_v2(static_cast<const uint8_t*>(image), len, &v2);
+  if (!e.empty()) return fail(EVQL_EIO, e);
+  *out_len = v2.size();
+  if (!dst || dst_cap < v2.size()) return fail(EVQL_EARG, "destination too small");
+  memcpy(dst, v2.data(), v2.size());
+  return EVQL_OK;
+}
+
 int evql_writer_write_file(const evql_writer_t* w, const char* path) {
   std::string e = w->w->write_file(path);
   if (!e.empty()) return fail(EVQL_EIO, e);

@@ -182,6 +182,18 @@ Status table_from_image(evql_ctx* ctx, const void* image, size_t len, bool keep_
                         evql_table** out) {
   std::unique_ptr<evql_table> t(new evql_table());
   t->ctx = ctx;
+  std::vector<uint8_t> transcoded;
+  {
+    // v0.1.0 files are re-encoded into the v0.2.0 page layout first (cstable_v1.cc)
+    const uint8_t* b = static_cast<const uint8_t*>(image);
+    if (len >= 6 && b[0] == 0x23 && b[1] == 0x17 && b[2] == 0x23 && b[3] == 0x17 &&
+        (uint32_t(b[4]) | (uint32_t(b[5]) << 8)) == 1) {
+      std::string verr = transcode_v1_to_v2(b, len, &transcoded);
+      if (!verr.empty()) return Status::error(EVQL_EIO, verr);
+      image = transcoded.data();
+      len = transcoded.size();
+    }
+  }
   std::string err = parse_cstable(static_cast<const uint8_t*>(image), len, &t->layout);
   if (!err.empty()) return Status::error(EVQL_EIO, err);
   t->image_len = len;

@@ -287,6 +287,14 @@ int evql_writer_put_string(evql_writer_t* w, int col, uint64_t n,
                            const char* bytes);
 int evql_writer_commit(evql_writer_t* w, uint64_t num_rows);
 const void* evql_writer_image(const evql_writer_t* w, uint64_t* len);
+/*
+ * Re-encodes a cstable v0.1.0 image (io/cstable/columns/v1/, cstable.cc:89-132)
+ * as v0.2.0; evql_table_open_* do this implicitly.  Host-only.  *out_len receives
+ * the size needed; the image is written when dst_cap is large enough, otherwise
+ * EVQL_EARG is returned with *out_len set (call with dst == NULL to size).
+ */
+int evql_cstable_upgrade(const void* image, uint64_t len, void* dst,
+                         uint64_t dst_cap, uint64_t* out_len);
 int evql_writer_write_file(const evql_writer_t* w, const char* path);
 void evql_writer_destroy(evql_writer_t* w);
 

@@ -202,6 +202,43 @@ def test_v010_fixture_oracle_equals_reference_reader(built):
     rr.close()
 
 
+def test_product_upgrade_of_v010_fixture_keeps_every_triple(built, tmp_path):
+    """evql_cstable_upgrade (what evql_table_open_* apply to v0.1.0 files): all 63
+    columns of the reference fixture keep their (rlevel, dlevel, value) streams,
+    storage types and level maxima, read back by the oracle (and, when built, by
+    the reference's own v0.2.0 reader)"""
+    path = os.path.join(T.GOLDEN, "testtbl.cst")
+    v2 = E.upgrade_image(open(path, "rb").read())
+    assert v2[:6] == b"\x23\x17\x23\x17\x02\x00"
+    p2 = str(tmp_path / "testtbl_v2.cst")
+    open(p2, "wb").write(v2)
+    readers = [O.TableReader(p2, "orc")] + ([O.TableReader(p2, "ref")] if O.have_ref() else [])
+    r1 = O.TableReader(path, "orc")
+    L = O.oracle()
+    for r2 in readers:
+        assert r2.num_rows == r1.num_rows == 213
+        c2 = {c["name"]: c for c in r2.columns()}
+        for c in r1.columns():
+            d = c2[c["name"]]
+            for f in ("logical_type", "storage_type", "rlevel_max", "dlevel_max"):
+                assert d[f] == c[f], (c["name"], f)
+            nvals = L.orc_table_column_num_values(r1.h, c["name"].encode())
+            kind = {K.COL_STRING: "string", K.COL_FLOAT: "float"}.get(c["logical_type"], "uint")
+            a = r1.read(c["name"], nvals, kind)
+            b = r2.read(c["name"], nvals, kind)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all(), c["name"]
+            if kind == "string":
+                assert a[3] == b[3], c["name"]
+            else:
+                assert (a[3] == b[3]).all(), c["name"]
+        r2.close()
+    r1.close()
+    with pytest.raises(E.EvqlError):
+        E.upgrade_image(v2)  # already v0.2.0
+    with pytest.raises(E.EvqlError):
+        E.upgrade_image(open(path, "rb").read()[:4000])  # truncated body
+
+
 def test_sha1_known_answers(built):
     # FIPS 180 / RFC 3174 vectors
     assert O.sha1(b"abc").hex() == "a9993e364706816aba3e25717850c26c9cd0d89d"

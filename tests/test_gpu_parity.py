@@ -310,6 +310,44 @@ def test_nested_scan_known_answers(ctx):
     t.close()
 
 
+def test_v010_fixture_opened_directly(ctx):
+    """the reference's own fixture file (cstable v0.1.0) through
+    evql_table_open_file: test/sql/00002 (count), 00001 (the time column, via a
+    group by) and the Runtime_test.cc nested answers, oracle reading the v0.1.0
+    file itself"""
+    import nested_tables as N
+    import os
+    path = os.path.join(T.GOLDEN, "testtbl.cst")
+    t = ctx.open_file(path)
+    assert t.num_rows == 213
+    S = N.NESTED_SCHEMA
+    tm = col("time")
+    nitems = col("event.search_query.num_result_items")
+    pos = col("event.search_query.result_items.position")
+    clicked = col("event.search_query.result_items.clicked")
+    got = t.query(Plan(S, select=[count(1)])).run()
+    assert got.rows() == [(213,)]
+    exp_times = [int(x) for x in open(os.path.join(
+        T.GOLDEN, "00001_test_column_reference_with_table_name_prefix.result.txt")
+    ).read().split("\n")[1:] if x]
+    got = t.query(Plan(S, select=[tm, count(1)], group_by=[tm])).run()
+    from collections import Counter
+    assert dict(got.rows()) == dict(Counter(exp_times))
+    for kw, known in [
+            (dict(select=[sum_(nitems)]), [(24793,)]),
+            (dict(select=[count(1), sum_(If(clicked, 1, 0))], where=pos.eq(6)), [(688, 2)]),
+            (dict(select=[pos, count(1), sum_(nitems), max_(tm)], group_by=[pos]), None)]:
+        plan = Plan(S, scan_mode=K.SCAN_NESTED, **kw)
+        exp = O.oracle_run(path, plan)
+        if known is not None:
+            assert exp.rows() == known
+        q = t.query(plan)
+        T.compare_results(q.run().rows(), exp.rows(), exp.types,
+                          key_cols=len(kw.get("group_by", [])))
+        q.close()
+    t.close()
+
+
 def test_nested_scan_synthetic_items(ctx):
     """config-5 shape: REPEATED RECORD items{position, price}, 0..8 per record"""
     import nested_tables as N
