@@ -97,6 +97,19 @@ def lib():
     L.evql_query_export_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
     L.evql_query_import_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.evql_query_reset.argtypes = [C.c_void_p]
+    L.evql_merge_create.argtypes = [C.POINTER(K.PlanDesc), C.POINTER(C.c_void_p)]
+    L.evql_merge_destroy.argtypes = [C.c_void_p]
+    L.evql_merge_add_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.evql_merge_add_rows.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p,
+                                      C.c_size_t, C.c_size_t]
+    L.evql_merge_num_groups.restype = C.c_uint64
+    L.evql_merge_num_groups.argtypes = [C.c_void_p]
+    L.evql_merge_column_count.restype = C.c_size_t
+    L.evql_merge_column_count.argtypes = [C.c_void_p]
+    L.evql_merge_column_type.restype = C.c_uint32
+    L.evql_merge_column_type.argtypes = [C.c_void_p, C.c_size_t]
+    L.evql_merge_next_batch.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(K.ColumnBuf),
+                                        C.POINTER(C.c_size_t)]
     L.evql_set_kernel_cache_dir.argtypes = [C.c_char_p]
     L.evql_compile_only.argtypes = [C.POINTER(K.PlanDesc), C.POINTER(K.ColumnInfo), C.c_int,
                                     C.c_char_p, C.POINTER(C.c_size_t)]
@@ -363,6 +376,51 @@ class Query:
         if self.h:
             lib().evql_query_destroy(self.h)
             self.h = None
+
+
+class Merge:
+    """mirrors csql::GroupByMergeExpression (groupby.cc:493-672) for partial
+    aggregates that arrive as bytes: add_frame()/add_rows(), then fetch_all()"""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.h = C.c_void_p()
+        _check(lib().evql_merge_create(C.byref(plan.desc), C.byref(self.h)))
+
+    def add_frame(self, payload):
+        buf = bytes(payload)
+        _check(lib().evql_merge_add_frame(self.h, buf, len(buf)))
+
+    def add_rows(self, keys_raw, data_raw, nrows):
+        _check(lib().evql_merge_add_rows(self.h, keys_raw, len(keys_raw), data_raw,
+                                         len(data_raw), nrows))
+
+    @property
+    def num_groups(self):
+        return lib().evql_merge_num_groups(self.h)
+
+    def fetch_all(self, batch=1024):
+        L = lib()
+        nc = L.evql_merge_column_count(self.h)
+        types = [L.evql_merge_column_type(self.h, i) for i in range(nc)]
+        raws = [b""] * nc
+        bufs = (K.ColumnBuf * max(1, nc))()
+        n = C.c_size_t()
+        while True:
+            _check(L.evql_merge_next_batch(self.h, batch, bufs, C.byref(n)))
+            if n.value == 0:
+                break
+            raws = [raws[i] + (C.string_at(bufs[i].data, bufs[i].size) if bufs[i].size else b"")
+                    for i in range(nc)]
+        return Result([unpack_svector(t, r) for t, r in zip(types, raws)], types, raws)
+
+    def close(self):
+        if self.h:
+            lib().evql_merge_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def compile_only(plan, columns, cache_dir=None):

@@ -432,6 +432,33 @@ uint32_t evql_query_record_words(const evql_query_t* q);
  * merge target of partial aggregates (GroupByMergeExpression, groupby.cc:528-637) */
 int evql_query_reset(evql_query_t* q);
 
+/*
+ * GroupByMergeExpression over partial aggregates that arrive as BYTES
+ * (groupby.cc:493-672): the coordinator's merge of PartialGroupBy rows from
+ * other nodes -- this build's EVQL_MODE_PARTIAL output or an unmodified
+ * reference node's.  Only plan->select_exprs is read.  Host-only (sequential
+ * LEB128 / SValue decoding, O(groups) work); partial tables resident on other
+ * GPUs are merged on the device with evql_query_import_groups instead.
+ *   add_frame: payload of one EVQL_OP_QUERY_PARTIALAGGR_RESULT frame
+ *              (varuint flags, varuint count, count x {20-B key, states...},
+ *              frames/query_partialaggr_result.cc:53-57)
+ *   add_rows:  the two STRING SVectors (key, data) of a PartialGroupBy
+ *              nextBatch, as evql_query_next_batch returns them
+ *   next_batch: as evql_query_next_batch (method_call per select expression;
+ *              non-aggregates carry the value decoded last, groupby.cc:606-610)
+ */
+typedef struct evql_merge evql_merge_t;
+int evql_merge_create(const evql_plan_desc_t* plan, evql_merge_t** out);
+void evql_merge_destroy(evql_merge_t* m);
+int evql_merge_add_frame(evql_merge_t* m, const void* payload, size_t len);
+int evql_merge_add_rows(evql_merge_t* m, const void* keys, size_t keys_len,
+                        const void* data, size_t data_len, size_t nrows);
+uint64_t evql_merge_num_groups(const evql_merge_t* m);
+size_t evql_merge_column_count(const evql_merge_t* m);
+uint32_t evql_merge_column_type(const evql_merge_t* m, size_t idx);
+int evql_merge_next_batch(evql_merge_t* m, size_t max_rows,
+                          evql_column_buf_t* cols, size_t* nrows);
+
 /* ------------------------------------------------------------------------ */
 /* build support                                                              */
 /* ------------------------------------------------------------------------ */

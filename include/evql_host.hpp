@@ -161,6 +161,67 @@ class GpuGroupByScan : public TableExpression {
   std::vector<evql_column_buf_t> bufs_;
 };
 
+// GroupByMergeExpression (groupby.h:130-178, groupby.cc:493-672) for partial
+// aggregates that arrive as bytes.  The reference pulls the frames itself from
+// its RPC scheduler inside execute(); here the transport hands them over with
+// addFrame() (or the two STRING SVectors of a partial operator with addPart())
+// before execute().
+class GroupByMerge : public TableExpression {
+ public:
+  explicit GroupByMerge(const evql_plan_desc_t& plan) : merge_(nullptr) {
+    int rc = evql_merge_create(&plan, &merge_);
+    if (rc == EVQL_ENOTSUP) throw NotLowerable(evql_last_error());
+    if (rc != EVQL_OK) throw std::runtime_error(evql_last_error());
+    const size_t n = evql_merge_column_count(merge_);
+    for (size_t i = 0; i < n; ++i) types_.push_back(SType(evql_merge_column_type(merge_, i)));
+    bufs_.resize(types_.size());
+  }
+  ~GroupByMerge() override { evql_merge_destroy(merge_); }
+  GroupByMerge(const GroupByMerge&) = delete;
+  GroupByMerge& operator=(const GroupByMerge&) = delete;
+
+  // payload of one EVQL_OP_QUERY_PARTIALAGGR_RESULT frame
+  ReturnCode addFrame(const void* payload, size_t len) {
+    int rc = evql_merge_add_frame(merge_, payload, len);
+    if (rc != EVQL_OK) return ReturnCode::error(status_code_string(rc), evql_last_error());
+    return ReturnCode::success();
+  }
+  // drains a PartialGroupBy-shaped operator (2 STRING columns: key, data)
+  ReturnCode addPart(TableExpression* partial) {
+    ReturnCode rc = partial->execute();
+    if (!rc.isSuccess()) return rc;
+    for (;;) {
+      SVector cols[2] = {SVector(SType::STRING), SVector(SType::STRING)};
+      size_t n = 0;
+      rc = partial->nextBatch(cols, &n);
+      if (!rc.isSuccess()) return rc;
+      if (n == 0) return ReturnCode::success();
+      int r = evql_merge_add_rows(merge_, cols[0].getData(), cols[0].getSize(), cols[1].getData(),
+                                  cols[1].getSize(), n);
+      if (r != EVQL_OK) return ReturnCode::error(status_code_string(r), evql_last_error());
+    }
+  }
+
+  ReturnCode execute() override { return ReturnCode::success(); }
+  ReturnCode nextBatch(SVector* columns, size_t* len) override {
+    size_t n = 0;
+    int rc = evql_merge_next_batch(merge_, kOutputBatchSize, bufs_.data(), &n);
+    if (rc != EVQL_OK) return ReturnCode::error(status_code_string(rc), evql_last_error());
+    for (size_t i = 0; i < types_.size(); ++i) {
+      if (bufs_[i].size) columns[i].append(bufs_[i].data, bufs_[i].size);
+    }
+    *len = n;
+    return ReturnCode::success();
+  }
+  size_t getColumnCount() const override { return types_.size(); }
+  SType getColumnType(size_t idx) const override { return types_.at(idx); }
+
+ private:
+  evql_merge_t* merge_;
+  std::vector<SType> types_;
+  std::vector<evql_column_buf_t> bufs_;
+};
+
 // pull cursor over any TableExpression (result_cursor.cc:34-100)
 class ResultCursor {
  public:

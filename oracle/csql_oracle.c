@@ -1101,3 +1101,6 @@ const char* orc_query_error(void) { return g_qerr; }
 
 /* nested scan: filled in by csql_nested.inc (kept separate for readability) */
 #include "csql_nested.inc"
+
+/* GroupByMergeExpression over partial-aggregate frames (kept separate too) */
+#include "csql_merge.inc"

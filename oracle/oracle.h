@@ -88,6 +88,13 @@ uint64_t orc_result_rows_scanned(const orc_result_t* r);
 uint64_t orc_result_rows_passed(const orc_result_t* r);
 const char* orc_query_error(void);
 
+/* GroupByMergeExpression (groupby.cc:528-672) over `nframes` partial-aggregate
+ * frame payloads (varuint flags, varuint count, rows); only plan->select_exprs
+ * is read.  orc_result_group_keys() returns the merged groups' SHA1 keys. */
+orc_result_t* orc_merge_frames(const evql_plan_desc_t* plan,
+                               const uint8_t* const* frames,
+                               const size_t* lens, int nframes);
+
 #ifdef __cplusplus
 }
 #endif

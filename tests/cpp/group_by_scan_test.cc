@@ -102,6 +102,51 @@ int main(int argc, char** argv) {
   plan.scan_mode = EVQL_SCAN_FLAT;
 
   int heartbeats = 0;
+  if (argc >= 3 && std::string(argv[2]) == "merge") {
+    // PartialGroupBy over two row ranges on the device -> GroupByMerge
+    // (scheduler.cc:117-162 fan-out, groupby.cc:528-672 merge)
+    try {
+      GroupByMerge merge(plan);
+      const uint64_t n = evql_table_num_rows(table), m = n / 3;
+      for (int part = 0; part < 2; ++part) {
+        evql_plan_desc_t pp = plan;
+        pp.group_mode = EVQL_MODE_PARTIAL;
+        pp.row_begin = part == 0 ? 0 : m;
+        pp.row_end = part == 0 ? m : n;
+        GpuGroupByScan partial(ctx, table, pp);
+        if (partial.getColumnCount() != 2 || partial.getColumnType(0) != SType::STRING) {
+          fprintf(stderr, "bad partial column metadata\n");
+          return 1;
+        }
+        ReturnCode rc = merge.addPart(&partial);
+        if (!rc.isSuccess()) {
+          fprintf(stderr, "addPart: %s\n", rc.getMessage().c_str());
+          return 1;
+        }
+      }
+      ResultCursor cursor(&merge);
+      std::map<uint64_t, std::pair<uint64_t, uint64_t>> rows;
+      while (cursor.nextBatch()) {
+        for (size_t i = 0; i < cursor.batchLength(); ++i) {
+          uint64_t k, s, cnt;
+          memcpy(&k, static_cast<const char*>(cursor.column(0).getData()) + 9 * i, 8);
+          memcpy(&s, static_cast<const char*>(cursor.column(1).getData()) + 9 * i, 8);
+          memcpy(&cnt, static_cast<const char*>(cursor.column(2).getData()) + 9 * i, 8);
+          rows[k] = {s, cnt};
+        }
+      }
+      printf("k;sum(a);count(1)\n");
+      for (const auto& r : rows) {
+        printf("%" PRIu64 ";%" PRIu64 ";%" PRIu64 "\n", r.first, r.second.first, r.second.second);
+      }
+    } catch (const std::exception& e) {
+      fprintf(stderr, "error: %s\n", e.what());
+      return 1;
+    }
+    evql_table_close(table);
+    evql_ctx_destroy(ctx);
+    return 0;
+  }
   try {
     GpuGroupByScan op(ctx, table, plan, [&heartbeats]() {
       ++heartbeats;

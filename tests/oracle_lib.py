@@ -295,27 +295,71 @@ def oracle_run(path_or_image, plan):
         if not r:
             raise RuntimeError(L.orc_query_error().decode())
         try:
-            nc = L.orc_result_num_columns(r)
-            nrows = L.orc_result_num_rows(r)
-            cols, types, raws = [], [], []
-            for i in range(nc):
-                sz = C.c_size_t()
-                p = L.orc_result_column_data(r, i, C.byref(sz))
-                raw = C.string_at(p, sz.value) if sz.value else b""
-                ty = L.orc_result_column_type(r, i)
-                types.append(ty)
-                raws.append(raw)
-                cols.append(unpack_svector(ty, raw))
-            keys = None
-            kp = L.orc_result_group_keys(r)
-            if kp:
-                keys = C.string_at(kp, 20 * nrows)
-            return OracleResult(cols, types, nrows, keys, L.orc_result_rows_scanned(r),
-                                L.orc_result_rows_passed(r), raws)
+            return _collect(L, r)
         finally:
             L.orc_result_free(r)
     finally:
         L.orc_table_close(t)
+
+
+def _collect(L, r):
+    nc = L.orc_result_num_columns(r)
+    nrows = L.orc_result_num_rows(r)
+    cols, types, raws = [], [], []
+    for i in range(nc):
+        sz = C.c_size_t()
+        p = L.orc_result_column_data(r, i, C.byref(sz))
+        raw = C.string_at(p, sz.value) if sz.value else b""
+        ty = L.orc_result_column_type(r, i)
+        types.append(ty)
+        raws.append(raw)
+        cols.append(unpack_svector(ty, raw))
+    keys = None
+    kp = L.orc_result_group_keys(r)
+    if kp:
+        keys = C.string_at(kp, 20 * nrows)
+    return OracleResult(cols, types, nrows, keys, L.orc_result_rows_scanned(r),
+                        L.orc_result_rows_passed(r), raws)
+
+
+def varuint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7f
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def partial_frame(keys, datas, flags=0):
+    """QUERY_PARTIALAGGR_RESULT payload (frames/query_partialaggr_result.cc:53-57):
+    varuint flags, varuint num_rows, then (20-B key, data) per row"""
+    return varuint(flags) + varuint(len(keys)) + b"".join(k + d for k, d in zip(keys, datas))
+
+
+def oracle_partial_frame(path_or_image, plan):
+    """runs `plan` (EVQL_MODE_PARTIAL) through the oracle and frames its rows"""
+    r = oracle_run(path_or_image, plan)
+    keys = [r.keys[20 * i:20 * i + 20] for i in range(r.nrows)]
+    return partial_frame(keys, r.columns[0])
+
+
+def oracle_merge(plan, frames):
+    """GroupByMergeExpression restatement over frame payloads"""
+    L = oracle()
+    L.orc_merge_frames.restype = C.c_void_p
+    L.orc_merge_frames.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
+                                   C.c_int]
+    arr = (C.c_char_p * len(frames))(*frames)
+    lens = (C.c_size_t * len(frames))(*[len(f) for f in frames])
+    r = L.orc_merge_frames(C.byref(plan.desc), arr, lens, len(frames))
+    if not r:
+        raise RuntimeError(L.orc_query_error().decode())
+    try:
+        return _collect(L, r)
+    finally:
+        L.orc_result_free(r)
 
 
 def sha1(data, which="orc"):

@@ -43,3 +43,7 @@ def test_cpp_operator_matches_oracle(built, tmp_path):
     lines = ["k;sum(a);count(1)"] + ["%d;%d;%d" % r for r in sorted(exp.rows())]
     assert out.stdout.strip().split("\n") == lines
     assert "heartbeats=2" in out.stderr
+    # the same query as two partial operators (row ranges) + GroupByMerge
+    out = subprocess.run([exe, path, "merge"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().split("\n") == lines

@@ -268,6 +268,42 @@ def test_partial_group_by_wire_rows(mixed):
         q.close()
 
 
+def test_partial_rows_from_the_gpu_merge_to_the_final_result(mixed):
+    """PartialGroupBy on the device over three row ranges -> wire rows ->
+    GroupByMergeExpression (evql_merge_*, groupby.cc:528-672) == the oracle's
+    whole-table GROUP BY; also merged by the oracle's own merge restatement"""
+    t, img, _ = mixed
+    cuts = [(0, 100_001), (100_001, 222_222), (222_222, 300_000)]
+    for kw, nkeys in (
+            (dict(select=[col("k"), sum_(col("a")), count(1), min_(col("nb")), mean(col("v"))],
+                  group_by=[col("k")], where=W), 1),
+            (dict(select=[col("ns"), col("f"), count(1), sum_(col("v")), max_(col("w"))],
+                  group_by=[col("ns"), col("f")]), 2)):
+        whole = Plan(T.MIXED_SCHEMA, **kw)
+        exp = O.oracle_run(img, whole)
+        m = E.Merge(whole)
+        frames = []
+        for lo, hi in cuts:
+            q = t.query(Plan(T.MIXED_SCHEMA, mode=K.MODE_PARTIAL, row_begin=lo, row_end=hi, **kw))
+            q.execute()
+            keys, datas = [], []
+            while True:
+                n, raw = q.next_batch(1024)
+                if n == 0:
+                    break
+                m.add_rows(raw[0], raw[1], n)
+                keys += E.plan.unpack_svector(K.T_STRING, raw[0])
+                datas += E.plan.unpack_svector(K.T_STRING, raw[1])
+            frames.append(O.partial_frame(keys, datas))
+            q.close()
+        got = m.fetch_all()
+        assert got.nrows == exp.nrows
+        T.compare_results(got.rows(), exp.rows(), exp.types, key_cols=nkeys)
+        om = O.oracle_merge(whole, frames)
+        T.compare_results(got.rows(), om.rows(), om.types, key_cols=nkeys, rel=0)
+        m.close()
+
+
 def test_nested_scan_known_answers(ctx):
     """Dremel flattening (CSTableScan, NO_AGGREGATION) on the device: the
     Runtime_test.cc:175-375 answers on the reference's fixture (re-encoded as
