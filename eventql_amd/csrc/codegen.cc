@@ -52,6 +52,21 @@ struct Emitter {
     return b;
   }
 
+  // string literals referenced by compares; declared at file scope by the caller
+  std::vector<std::string> string_literals;
+
+  std::string str_operand(const ExprPtr& x) {
+    char b[96];
+    if (x->kind == Expr::INPUT) {
+      snprintf(b, sizeof(b), "evql_col_str(A, A.col[%u], row)", x->input);
+      return b;
+    }
+    snprintf(b, sizeof(b), "evql_lit_str(evql_slit%zu, %zuu)", string_literals.size(),
+             x->lit_str.size());
+    string_literals.push_back(x->lit_str);
+    return b;
+  }
+
   // payload reinterpreted as raw 64 bits
   static std::string as_bits(const Val& x) {
     switch (x.type) {
@@ -102,10 +117,28 @@ struct Emitter {
       case Expr::CALL:
         break;
     }
+    const int fam = e->family, ts = e->type_slot;
+    if (ts == EVQL_TS_STRING && fam >= EVQL_FAM_CMP && fam <= EVQL_FAM_GTE) {
+      // operands are string columns / literals (planner.cc strings_lowerable)
+      const std::string l = str_operand(e->args[0]), r = str_operand(e->args[1]);
+      const std::string c = "evql_str_cmp(" + l + ", " + r + ")";
+      std::string rhs;
+      switch (fam) {
+        case EVQL_FAM_EQ: rhs = "evql_str_eq(" + l + ", " + r + ")"; break;
+        case EVQL_FAM_NEQ: rhs = "(!evql_str_eq(" + l + ", " + r + "))"; break;
+        case EVQL_FAM_LT: rhs = "(" + c + " < 0)"; break;
+        case EVQL_FAM_LTE: rhs = "(" + c + " <= 0)"; break;
+        case EVQL_FAM_GT: rhs = "(" + c + " > 0)"; break;
+        case EVQL_FAM_GTE: rhs = "(" + c + " >= 0)"; break;
+        default: rhs = "((i64) " + c + ")";
+      }
+      std::string t = fresh("t");
+      o << ind << "const " << ctype(e->type) << " " << t << " = " << rhs << ";\n";
+      return {t, "0u", e->type};
+    }
     std::vector<Val> a;
     for (const auto& x : e->args) a.push_back(emit(x));
     std::string t = fresh("t");
-    const int fam = e->family, ts = e->type_slot;
     std::string rhs;
     auto bin = [&](const char* opr) { return "(" + a[0].v + " " + opr + " " + a[1].v + ")"; };
     switch (fam) {

@@ -20,6 +20,7 @@ struct ColAccess {
   bool bool_normalize = false;  // BOOLEAN column: value = (raw > 0)
   bool from_uint_to_float = false;  // FLOAT64 stype over a uint column: (double) u
   bool string_hash = false;   // STRING column materialised as hash64
+  bool string_bytes = false;  // ... and compared bytewise on the device (strpos array)
   int layout_index = -1;      // index into TableLayout::columns
 };
 

@@ -38,6 +38,9 @@ struct EvqlColArg {
   const u64* soa;    // pre-decoded values (one u64 per row) or NULL
   const u8* tags;    // pre-decoded tag bytes (STAG_NULL) per row or NULL
   u64 npages;
+  // STRING columns compared bytewise: per row (len << 40) | position of the first
+  // byte in the column's logical byte stream (pages laid end to end), or NULL
+  const u64* strpos;
 };
 
 struct EvqlArgs {
@@ -150,6 +153,47 @@ __device__ __forceinline__ u32 evql_bitpacked_rt(const u8* image, const u64* pag
 
 __device__ __forceinline__ bool evql_row_filter(const u8* bits, u64 len, u64 row) {
   return row < len && ((bits[row >> 3] >> (row & 7)) & 1);
+}
+
+// ---------------------------------------------------------------------------
+// string operands of eq / neq / lt / lte / gt / gte / cmp (boolean.cc:150-166,
+// 237-251, 441-452 ...).  A column value lives in the STRING_PLAIN page stream
+// (512 KiB pages, bytes may straddle pages); a literal is a constant array.
+// ---------------------------------------------------------------------------
+struct EvqlStr {
+  const u8* base;    // image (column value) or the literal's bytes
+  const u64* pages;  // page offsets of the column stream; NULL for a literal
+  u64 pos;
+  u32 len;
+};
+__device__ __forceinline__ EvqlStr evql_col_str(const EvqlArgs& A, const EvqlColArg& c, u64 row) {
+  const u64 sp = c.strpos[row];
+  return EvqlStr{A.image, c.pages, sp & 0xFFFFFFFFFFull, (u32) (sp >> 40)};
+}
+__device__ __forceinline__ EvqlStr evql_lit_str(const u8* bytes, u32 len) {
+  return EvqlStr{bytes, nullptr, 0, len};
+}
+__device__ __forceinline__ u32 evql_str_byte(const EvqlStr& s, u32 i) {
+  const u64 p = s.pos + i;
+  return s.pages ? s.base[s.pages[p >> 19] + (p & 0x7ffffu)] : s.base[p];
+}
+// memcmp-equality (eq_string / neq_string)
+__device__ __forceinline__ bool evql_str_eq(const EvqlStr& a, const EvqlStr& b) {
+  if (a.len != b.len) return false;
+  for (u32 i = 0; i < a.len; ++i) {
+    if (evql_str_byte(a, i) != evql_str_byte(b, i)) return false;
+  }
+  return true;
+}
+// strncmp over the common prefix (stops at a NUL both sides share), then length
+__device__ __forceinline__ int evql_str_cmp(const EvqlStr& a, const EvqlStr& b) {
+  const u32 n = a.len < b.len ? a.len : b.len;
+  for (u32 i = 0; i < n; ++i) {
+    const u32 x = evql_str_byte(a, i), y = evql_str_byte(b, i);
+    if (x != y) return x < y ? -1 : 1;
+    if (x == 0) break;
+  }
+  return a.len < b.len ? -1 : (a.len > b.len ? 1 : 0);
 }
 
 __device__ __forceinline__ double evql_as_f64(u64 v) { return __longlong_as_double((i64) v); }

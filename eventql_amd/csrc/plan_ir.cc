@@ -406,6 +406,8 @@ std::string eval_expr(const ExprPtr& e, const std::vector<Value>& inputs,
         }
         case EVQL_TS_STRING:
           c = str_cmp(a[0].str, a[1].str);
+          // eq / neq use memcmp (boolean.cc:237-251, 357-371)
+          if (fam == EVQL_FAM_EQ || fam == EVQL_FAM_NEQ) c = a[0].str == a[1].str ? 0 : 1;
           break;
         default: {
           uint64_t l = a[0].bits, r = a[1].bits;

@@ -49,16 +49,41 @@ bool has_input(const ExprPtr& e) {
 
 bool is_bare_input(const ExprPtr& e) { return e && e->kind == Expr::INPUT; }
 
-// strings may only flow through untouched (bare column refs)
-bool strings_only_bare(const ExprPtr& e) {
+bool is_string_compare(const ExprPtr& e) {
+  return e->kind == Expr::CALL && e->type_slot == EVQL_TS_STRING && e->family >= EVQL_FAM_CMP &&
+         e->family <= EVQL_FAM_GTE;
+}
+
+// Strings on the device: a bare column reference flows through untouched (as
+// its hash, for keys / first-row values), and string columns / literals may be
+// the operands of eq / neq / lt / lte / gt / gte / cmp (bytewise compare in the
+// kernel).  Anything else that produces or consumes a string (concat, IF over
+// strings, to_string ...) is not lowered.
+bool strings_lowerable(const ExprPtr& e, bool root = true) {
   if (!e) return true;
-  if (e->kind == Expr::INPUT) return true;
-  if (e->type == EVQL_T_STRING) return false;
+  if (e->type == EVQL_T_STRING) return root && e->kind == Expr::INPUT;
+  if (is_string_compare(e)) {
+    for (const auto& a : e->args) {
+      if (a->type != EVQL_T_STRING) return false;
+      if (a->kind != Expr::INPUT && a->kind != Expr::LITERAL) return false;
+    }
+    return true;
+  }
   for (const auto& a : e->args) {
-    if (a->type == EVQL_T_STRING) return false;
-    if (!strings_only_bare(a)) return false;
+    if (!strings_lowerable(a, false)) return false;
   }
   return true;
+}
+
+// marks the string columns whose bytes the kernel has to reach
+void mark_string_bytes(const ExprPtr& e, std::vector<ColAccess>* cols) {
+  if (!e) return;
+  if (is_string_compare(e)) {
+    for (const auto& a : e->args) {
+      if (a->kind == Expr::INPUT && a->input < cols->size()) (*cols)[a->input].string_bytes = true;
+    }
+  }
+  for (const auto& a : e->args) mark_string_bytes(a, cols);
 }
 
 // can the value carry STAG_NULL?  (pure functions always produce tag 0)
@@ -217,9 +242,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     if (q->where.is_aggregate || q->where.return_type != EVQL_T_BOOL) {
       return Status::error(EVQL_EARG, "WHERE must be a non-aggregate boolean expression");
     }
-    if (expr_uses_strings(q->where.call)) return unsup("string predicates are not lowered yet");
+    if (!strings_lowerable(q->where.call)) return unsup("string expression is not lowerable");
     q->has_where = true;
     kp.where = q->where.call;
+    mark_string_bytes(kp.where, &kp.cols);
   }
   q->scan_select.resize(plan->n_scan_select);
   std::vector<ExprPtr> scan_out;
@@ -227,7 +253,7 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     err = lower_program(plan->scan_select[i], &q->scan_select[i], &u);
     if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
     if (q->scan_select[i].is_aggregate) return unsup("aggregate in the scan select list");
-    if (!strings_only_bare(q->scan_select[i].call)) return unsup("string expressions are not lowered yet");
+    if (!strings_lowerable(q->scan_select[i].call)) return unsup("string expression is not lowerable");
     scan_out.push_back(q->scan_select[i].call);
   }
   q->group.resize(plan->n_group);
@@ -237,7 +263,8 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     if (q->group[i].is_aggregate) return Status::error(EVQL_EARG, "aggregate in GROUP BY");
     ExprPtr g = inline_inputs(q->group[i].call, scan_out, &err);
     if (!err.empty()) return Status::error(EVQL_EARG, err);
-    if (!strings_only_bare(g)) return unsup("string expressions are not lowered yet");
+    if (!strings_lowerable(g)) return unsup("string expression is not lowerable");
+    mark_string_bytes(g, &kp.cols);
     kp.group.push_back(g);
   }
   if (plan->n_group == 0) {
@@ -264,14 +291,15 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
         if (lp.acc_args.size() != 1) return Status::error(EVQL_EARG, "aggregate arity");
         a.arg = inline_inputs(lp.acc_args[0], scan_out, &err);
         if (!err.empty()) return Status::error(EVQL_EARG, err);
-        if (expr_uses_strings(a.arg)) return unsup("string aggregates are not lowered");
+        if (!strings_lowerable(a.arg, false)) return unsup("string aggregates are not lowered");
+        mark_string_bytes(a.arg, &kp.cols);
       } else if (lp.acc_args.size() == 1 && lp.acc_args[0]->kind == Expr::CALL &&
                  lp.acc_args[0]->family == EVQL_FAM_TO_NIL) {
         // count(x): evaluate x for its side effects (division by zero) only when
         // it is not a plain column / literal
         const ExprPtr& inner = lp.acc_args[0]->args[0];
         if (inner->kind == Expr::CALL || inner->kind == Expr::IF) {
-          if (expr_uses_strings(inner)) return unsup("string expressions are not lowered yet");
+          if (!strings_lowerable(inner, false)) return unsup("string expression is not lowerable");
         }
       }
       a.first_word = int(kp.states.size());
@@ -315,7 +343,7 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
       if (has_agg_get(lp.call)) return Status::error(EVQL_EARG, "malformed aggregate program");
       ExprPtr e = inline_inputs(lp.call, scan_out, &err);
       if (!err.empty()) return Status::error(EVQL_EARG, err);
-      if (!strings_only_bare(e)) return unsup("string expressions are not lowered yet");
+      if (!strings_lowerable(e)) return unsup("string expression is not lowerable");
       if (kp.key_mode == KEY_EXACT && expr_equal(e, kp.group[0])) {
         q->select_passthrough[i] = true;  // value == the group key itself
       } else if (!has_input(e)) {

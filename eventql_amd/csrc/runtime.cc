@@ -227,6 +227,7 @@ evql_table::~evql_table() {
   for (auto& kv : materialized) {
     if (kv.second.d_values) hipFree(kv.second.d_values);
     if (kv.second.d_tags) hipFree(kv.second.d_tags);
+    if (kv.second.d_strpos) hipFree(kv.second.d_strpos);
   }
 }
 
@@ -313,11 +314,31 @@ static Status scan_string_column(const evql_table* t, const ColumnLayout& c,
   return Status();
 }
 
+// per-row (len << 40 | position) of a string column, for bytewise compares in
+// the fused kernel (evql_col_str)
+static Status upload_string_positions(evql_table* t, MaterializedColumn* m) {
+  if (m->d_strpos) return Status();
+  const uint64_t n = t->layout.num_rows;
+  std::vector<uint64_t> sp(padded_rows(n), 0);
+  for (uint64_t r = 0; r < n; ++r) {
+    if (m->str_off[r] >> 40 || m->str_len[r] >> 24) {
+      return Status::error(EVQL_ENOTSUP, "string column too large for device compares");
+    }
+    sp[r] = m->str_off[r] | (uint64_t(m->str_len[r]) << 40);
+  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_strpos), sp.size() * 8));
+  HIP_TRY(hipMemcpy(m->d_strpos, sp.data(), sp.size() * 8, hipMemcpyHostToDevice));
+  return Status();
+}
+
 static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* bits_out) {
   evql_ctx* ctx = t->ctx;
   const ColumnLayout& c = t->layout.columns[ca.layout_index];
   (void) bits_out;
-  if (t->materialized.count(c.name)) return Status();
+  if (t->materialized.count(c.name)) {
+    if (ca.string_bytes) return upload_string_positions(t, &t->materialized[c.name]);
+    return Status();
+  }
   MaterializedColumn m;
   const uint64_t n = t->layout.num_rows;
   const uint64_t np = padded_rows(n);
@@ -346,6 +367,7 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
     hipFree(d_off);
     hipFree(d_len);
     t->materialized[c.name] = std::move(m);
+    if (ca.string_bytes) return upload_string_positions(t, &t->materialized[c.name]);
     return Status();
   }
 
@@ -809,6 +831,7 @@ Status query_launch(evql_query* q) {
       const MaterializedColumn& m = t->materialized[c.name];
       a.col[i].soa = m.d_values;
       a.col[i].tags = m.d_tags;
+      a.col[i].strpos = m.d_strpos;
     }
   }
   if (kp.partitioned && a.ntiles > 0) {

@@ -20,6 +20,7 @@ struct HostColArg {
   const uint64_t* soa;
   const uint8_t* tags;
   uint64_t npages;
+  const uint64_t* strpos;
 };
 static const uint32_t EVQL_MAX_COLS_HOST = 16;
 struct HostArgs {
@@ -82,6 +83,8 @@ struct MaterializedColumn {
   uint64_t* d_values = nullptr;
   uint8_t* d_tags = nullptr;
   bool string_hash = false;
+  // strings compared on the device: (len << 40) | byte position, per row
+  uint64_t* d_strpos = nullptr;
   // strings: host-side positions for result emission
   std::vector<uint64_t> str_off;
   std::vector<uint32_t> str_len;

@@ -218,6 +218,11 @@ static int call_pure(int64_t fn, vmstack_t* s) {
           pop_str(s, &rp, &rl);
           pop_str(s, &lp, &ll);
           c = str_cmp(lp, ll, rp, rl);
+          /* eq_string / neq_string compare with memcmp (boolean.cc:237-251,
+           * 357-371), which sees past an embedded NUL */
+          if (fam == EVQL_FAM_EQ || fam == EVQL_FAM_NEQ) {
+            c = (ll == rl && memcmp(lp, rp, ll) == 0) ? 0 : 1;
+          }
           break;
         }
         default:

@@ -10,7 +10,7 @@ import pytest
 
 import eventql_amd as E
 from eventql_amd import capi as K, bench_plans as B
-from eventql_amd.plan import Plan, col, count, sum_, min_, mean, If, CompileError, Agg
+from eventql_amd.plan import Plan, col, count, sum_, min_, mean, If, CompileError, Agg, Call
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -88,6 +88,26 @@ def test_compile_expression_coverage(built, tmp_path):
     cols = _cols("k", "a", "b", "v", a=dict(storage_type=K.ENC_UINT32_BITPACKED, bits=17),
                  b=dict(storage_type=K.ENC_UINT32_PLAIN))
     assert E.compile_only(plan, cols, cache_dir=str(tmp_path)) > 4000
+
+
+def test_compile_string_predicates(built, tmp_path):
+    """eq / neq / lt / lte / gt / gte / cmp on string columns and literals lower to
+    bytewise compares in the kernel; other string expressions stay ENOTSUP"""
+    S = dict(k=K.T_UINT64, s=K.T_STRING, s2=K.T_STRING)
+    cols = [dict(name="k", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+            dict(name="s", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN),
+            dict(name="s2", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN,
+                 dlevel_max=1)]
+    s, s2, k = col("s"), col("s2"), col("k")
+    plan = Plan(S, select=[k, count(1), sum_(If(s2 >= "m", 1, 0))], group_by=[k],
+                where=(s.eq("g5") | (s < s2)) & s2.neq("") & (Call("cmp", s, s2) < 1))
+    assert E.compile_only(plan, cols, cache_dir=str(tmp_path)) > 4000
+    plan = Plan(S, select=[s < "g5", count(1)], group_by=[s < "g5"])
+    assert E.compile_only(plan, cols, cache_dir=str(tmp_path)) > 4000
+    bad = Plan(S, select=[count(1)], where=If(k > 1, s, s2).eq("x"))
+    with pytest.raises(E.EvqlError) as ei:
+        E.compile_only(bad, cols)
+    assert ei.value.code == K.EVQL_ENOTSUP
 
 
 def test_not_lowerable_plans_are_reported(built):

@@ -152,6 +152,53 @@ def test_string_keys(mixed):
           group_by=[col("k"), col("s")])
 
 
+def test_string_predicates(mixed):
+    """boolean.cc string compares (eq/neq = memcmp, ordering = strncmp then
+    length; tags ignored, NULL = ""), bytewise in the kernel over the
+    STRING_PLAIN page stream"""
+    t, img, _ = mixed
+    s, ns, a, k = col("s"), col("ns"), col("a"), col("k")
+    check(t, img, key_cols=0, select=[count(1), sum_(a)], where=s.eq("g5"))
+    check(t, img, key_cols=0, select=[count(1), sum_(a)], where=s.neq("g77") & (a > 30000))
+    check(t, img, select=[k, count(1)], group_by=[k], where=(s < "g5") | (s >= "g95"))
+    check(t, img, key_cols=0, select=[count(1)], where=ns.eq(""))          # NULL strings read ""
+    check(t, img, key_cols=0, select=[count(1)], where=ns > "s3")
+    check(t, img, key_cols=0, select=[count(1)], where=ns <= "s30")
+    check(t, img, key_cols=0, select=[count(1)], where=s < ns)             # column vs column
+    check(t, img, key_cols=0, select=[count(1)], where=Call("cmp", s, ns) > 0)
+    check(t, img, select=[s < "g5", count(1), sum_(If(ns.eq("s7"), a, 0))], group_by=[s < "g5"])
+    check(t, img, select=[ns, count(1)], group_by=[ns], where=ns.neq("s1") & s.neq("g1"))
+    check(t, img, key_cols=0, select=[count(1)], where=s.eq("no such value"))
+
+
+def test_string_predicates_over_page_straddling_values(ctx):
+    """values longer than a few bytes, embedded NULs, empty strings, and 2 MiB of
+    string data so that values straddle the 512 KiB pages"""
+    n = 60_000
+    rng = np.random.default_rng(5)
+    words = [b"", b"a", b"a\0b", b"a\0c", b"ab", b"abc" * 9, b"\xff\xfe", b"zebra" * 13, b"a\0"]
+    vals = [words[i] for i in rng.integers(0, len(words), n)]
+    w = E.Writer([dict(name="s", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN),
+                  dict(name="x", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN)])
+    w.put("s", vals)
+    w.put("x", np.arange(n, dtype=np.uint64))
+    w.commit(n)
+    img = w.image()
+    w.close()
+    assert len(img) > 3 * 512 * 1024
+    t = ctx.open_image(img)
+    S = dict(s=K.T_STRING, x=K.T_UINT64)
+    s = col("s")
+    for lit_ in (b"", b"a", b"a\0b", b"a\0c", b"ab", b"abc" * 9, b"abd", b"\xff", b"zebra" * 13):
+        for op in ("eq", "neq", "lt", "lte", "gt", "gte"):
+            plan = Plan(S, select=[count(1), sum_(col("x"))], where=Call(op, s, lit(lit_)))
+            exp = O.oracle_run(img, plan)
+            q = t.query(plan)
+            assert q.run().rows() == exp.rows(), (lit_, op)
+            q.close()
+    t.close()
+
+
 def test_multi_column_keys_and_first_row(mixed):
     t, img, _ = mixed
     check(t, img, key_cols=2, select=[col("k"), col("f"), count(1), sum_(col("a"))],
