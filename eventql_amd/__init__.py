@@ -97,6 +97,11 @@ def lib():
     L.evql_query_export_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
     L.evql_query_import_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.evql_query_reset.argtypes = [C.c_void_p]
+    L.evql_lsm_chain_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.evql_lsm_chain_destroy.argtypes = [C.c_void_p]
+    L.evql_lsm_chain_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _u8p, C.c_uint64]
+    L.evql_lsm_chain_build.argtypes = [C.c_void_p]
+    L.evql_lsm_chain_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(_u8p), _u64p, _u64p]
     L.evql_merge_create.argtypes = [C.POINTER(K.PlanDesc), C.POINTER(C.c_void_p)]
     L.evql_merge_destroy.argtypes = [C.c_void_p]
     L.evql_merge_add_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -376,6 +381,43 @@ class Query:
         if self.h:
             lib().evql_query_destroy(self.h)
             self.h = None
+
+
+class LsmChain:
+    """row filters of a newest-first chain of LSM tables, built on the device
+    (PartitionCursor::openNextTable, partition_cursor.cc:160-195)"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.tables = []
+        self.h = C.c_void_p()
+        _check(lib().evql_lsm_chain_create(ctx.h, C.byref(self.h)))
+
+    def add(self, table, has_skip_column=False, arena_skiplist=None):
+        sk = None if arena_skiplist is None else np.ascontiguousarray(arena_skiplist, np.uint8)
+        _check(lib().evql_lsm_chain_add(self.h, table.h, int(has_skip_column), _ptr(sk, _u8p),
+                                        0 if sk is None else len(sk)))
+        self.tables.append(table)
+
+    def build(self):
+        _check(lib().evql_lsm_chain_build(self.h))
+
+    def filter(self, idx):
+        """(bool array per row, rows kept) of the idx-th table"""
+        bits = _u8p()
+        n = C.c_uint64()
+        kept = C.c_uint64()
+        _check(lib().evql_lsm_chain_filter(self.h, idx, C.byref(bits), C.byref(n), C.byref(kept)))
+        raw = np.frombuffer(C.string_at(bits, (n.value + 63) // 64 * 8), np.uint8)
+        return np.unpackbits(raw, bitorder="little")[:n.value].astype(bool), kept.value
+
+    def close(self):
+        if self.h:
+            lib().evql_lsm_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 class Merge:

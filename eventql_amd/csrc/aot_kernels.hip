@@ -290,6 +290,91 @@ __global__ void k_string_hash(const u8* image, const u64* pages, const u64* offs
   }
 }
 
+// ---- LSM row filters ----------------------------------------------------------------
+// The reference walks the chain sequentially with a std::set of updated ids
+// (partition_cursor.cc:160-195): a row is dropped when it is skipped or when an
+// EARLIER kept row with the same id was an update.  Equivalently, per id, rows are
+// kept up to and including the first non-skipped update in scan order -- which two
+// data-parallel passes compute with a hash table of minimum positions.
+__device__ __forceinline__ bool lsm_row(const LsmArgs& a, u64 r, u64* id, bool* upd, bool* bad) {
+  bool skip = false;
+  if (a.has_skip) skip = rt_column_value(a.image, a.skip, r) != 0;
+  if (a.arena_skip) skip = a.arena_skip[r] != 0;
+  const u64 sp = a.id_pos[r];
+  const u64 pos = sp & 0xFFFFFFFFFFull;
+  const u32 len = (u32) (sp >> 40);
+  *bad = len != 20;  // SHA1Hash(data, size) raises otherwise (util/SHA1.cc:79-85)
+  id[0] = id[1] = id[2] = 0;
+  for (u32 k = 0; k < 20 && k < len; ++k) {
+    id[k >> 3] |= (u64) vbyte(a.image, (const u64*) a.id.pages, pos + k) << (8 * (k & 7));
+  }
+  // the all-ones word marks a free slot
+  if (id[0] == EVQL_EMPTY) id[0] = EVQL_EMPTY - 1;
+  if (id[1] == EVQL_EMPTY) id[1] = EVQL_EMPTY - 1;
+  *upd = rt_column_value(a.image, a.is_update, r) != 0;
+  return skip;
+}
+
+__global__ void __launch_bounds__(kBlock) k_lsm_insert(LsmArgs a) {
+  const u64 mask = a.cap - 1;
+  for (u64 r = (u64) blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows;
+       r += (u64) gridDim.x * blockDim.x) {
+    u64 id[3];
+    bool upd, bad;
+    const bool skip = lsm_row(a, r, id, &upd, &bad);
+    if (bad) {
+      atomicAdd((unsigned long long*) &a.counters[1], 1ull);
+      continue;
+    }
+    if (skip || !upd) continue;
+    u64 h = evql_mix64(id[0] ^ evql_mix64(id[1] + id[2])) & mask;
+    for (u64 probe = 0; probe < a.cap; ++probe, h = (h + 1) & mask) {
+      u64 prev = atomicCAS((unsigned long long*) &a.tab[h], EVQL_EMPTY, id[0]);
+      if (prev != EVQL_EMPTY && prev != id[0]) continue;
+      prev = atomicCAS((unsigned long long*) &a.tab[a.cap + h], EVQL_EMPTY, id[1]);
+      if (prev != EVQL_EMPTY && prev != id[1]) continue;
+      prev = atomicCAS((unsigned long long*) &a.tab[2 * a.cap + h], EVQL_EMPTY, id[2]);
+      if (prev != EVQL_EMPTY && prev != id[2]) continue;
+      atomicMin((unsigned long long*) &a.tab[3 * a.cap + h], a.pos0 + r);
+      break;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_lsm_filter(LsmArgs a) {
+  const u64 mask = a.cap - 1;
+  const u64 nwords = (a.nrows + 63) / 64;
+  const u64 wave = ((u64) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const u64 nwaves = ((u64) gridDim.x * blockDim.x) >> 6;
+  const u32 lane = threadIdx.x & 63;
+  for (u64 w = wave; w < nwords; w += nwaves) {
+    const u64 r = w * 64 + lane;
+    bool keep = false;
+    if (r < a.nrows) {
+      u64 id[3];
+      bool upd, bad;
+      const bool skip = lsm_row(a, r, id, &upd, &bad);
+      keep = !skip && !bad;
+      if (keep) {
+        u64 h = evql_mix64(id[0] ^ evql_mix64(id[1] + id[2])) & mask;
+        for (u64 probe = 0; probe < a.cap; ++probe, h = (h + 1) & mask) {
+          const u64 k0 = a.tab[h];
+          if (k0 == EVQL_EMPTY) break;
+          if (k0 == id[0] && a.tab[a.cap + h] == id[1] && a.tab[2 * a.cap + h] == id[2]) {
+            keep = a.pos0 + r <= a.tab[3 * a.cap + h];
+            break;
+          }
+        }
+      }
+    }
+    const u64 m = __ballot(keep);
+    if (lane == 0) {
+      a.bits[w] = m;
+      if (m) atomicAdd((unsigned long long*) &a.counters[0], (unsigned long long) __popcll(m));
+    }
+  }
+}
+
 // ---- synthetic table -----------------------------------------------------------------
 // one thread generates 128 consecutive rows (= one bit-packed block)
 __global__ void __launch_bounds__(kBlock) k_synth(const SynthArgs* ap, u64 nchunks) {
@@ -596,6 +681,18 @@ hipError_t launch_defined_from_levels(const uint8_t* dlevels, uint32_t dmax, uin
   if (ntiles == 0) return hipSuccess;
   hipLaunchKernelGGL(k_defined_from_levels, dim3((unsigned) ntiles), dim3(kBlock), 0, s, dlevels,
                      dmax, (u64) nslots, tags, (u64*) tile_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_lsm_insert(const LsmArgs& a, hipStream_t s) {
+  if (a.nrows == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_lsm_insert, dim3(grid_for(a.nrows)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_lsm_filter(const LsmArgs& a, hipStream_t s) {
+  if (a.nrows == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_lsm_filter, dim3(grid_for(a.nrows)), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

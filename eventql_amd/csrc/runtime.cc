@@ -464,6 +464,60 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
 // svalue.cc:154-160 -- NOT a NULL tag).  The number of real slots is where record
 // number `num_rows` would start (bit-packed streams are zero-padded).
 // ---------------------------------------------------------------------------
+// Row-addressable view of one flat column for the AOT kernels (lsm.cc): direct
+// page access where the encoding allows it, the cached SoA decode otherwise.
+// For STRING columns *strpos receives the device array of (len << 40 | position).
+Status table_rt_column(evql_table* t, const std::string& name, RtColumn* out,
+                       const uint64_t** strpos) {
+  int li = -1;
+  for (size_t k = 0; k < t->layout.columns.size(); ++k) {
+    if (t->layout.columns[k].name == name) li = int(k);
+  }
+  if (li < 0) return Status::error(EVQL_EARG, "column not found: " + name);
+  const ColumnLayout& cl = t->layout.columns[li];
+  if (cl.rlevel_max > 0) return Status::error(EVQL_ENOTSUP, "repeated column: " + name);
+  ColAccess c;
+  c.name = name;
+  c.layout_index = li;
+  c.stype = EVQL_T_UINT64;
+  *out = RtColumn{};
+  out->pages = t->d_pages[li][0];
+  if (cl.logical_type == ColumnType::STRING) {
+    c.stype = EVQL_T_STRING;
+    c.mode = ColAccess::SOA;
+    c.string_hash = c.string_bytes = c.has_tags = true;
+  } else {
+    switch (cl.storage_type) {
+      case ColumnEncoding::UINT64_PLAIN:
+      case ColumnEncoding::FLOAT_IEEE754: c.mode = ColAccess::PLAIN64; break;
+      case ColumnEncoding::UINT32_PLAIN: c.mode = ColAccess::PLAIN32; break;
+      case ColumnEncoding::UINT32_BITPACKED:
+      case ColumnEncoding::BOOLEAN_BITPACKED: c.mode = ColAccess::BITPACKED; break;
+      default: c.mode = ColAccess::SOA;
+    }
+    if (cl.dlevel_max > 0) {
+      c.mode = ColAccess::SOA;
+      c.has_tags = true;
+    }
+  }
+  if (c.mode == ColAccess::BITPACKED) {
+    uint32_t maxv = 0;
+    if (!cl.data_pages.empty()) {
+      HIP_TRY(hipMemcpy(&maxv, t->d_image + cl.data_pages[0].offset, 4, hipMemcpyDeviceToHost));
+    }
+    out->bits = cl.data_pages.empty() ? 0 : bitpack_width(maxv);
+  } else if (c.mode == ColAccess::SOA) {
+    Status st = materialize_column(t, c, nullptr);
+    if (!st.ok()) return st;
+    const MaterializedColumn& m = t->materialized[name];
+    out->soa = m.d_values;
+    out->tags = m.d_tags;
+    if (strpos) *strpos = m.d_strpos;
+  }
+  out->mode = uint32_t(c.mode);
+  return Status();
+}
+
 static uint64_t level_stream_capacity(const std::vector<PageRef>& pages, uint32_t bits) {
   if (bits == 0) return 0;
   uint64_t blocks = 0;

@@ -167,4 +167,7 @@ Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out,
                       bool load_module);
 Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan,
                          evql_query* q, bool* unsupported);
+// row-addressable device view of a flat column (direct pages or cached SoA decode)
+Status table_rt_column(evql_table* t, const std::string& name, RtColumn* out,
+                       const uint64_t** strpos);
 }  // namespace evql

@@ -460,6 +460,34 @@ int evql_merge_next_batch(evql_merge_t* m, size_t max_rows,
                           evql_column_buf_t* cols, size_t* nrows);
 
 /* ------------------------------------------------------------------------ */
+/* LSM row filters (PartitionCursor::openNextTable,                           */
+/* server/sql/partition_cursor.cc:83-226)                                     */
+/* ------------------------------------------------------------------------ */
+/*
+ * A partition is a chain of cstables scanned newest first: head arena,
+ * compacting arena, then the LSM files from the newest to the oldest.  A row is
+ * scanned unless it is skipped (`__lsm_skip`, or the arena's skiplist) or a row
+ * in front of it with the same `__lsm_id` was a kept update
+ * (`__lsm_is_update`).  _build computes every table's filter on the device;
+ * _filter hands out the bitmap (bit r of byte r/8 set <=> row r is scanned) in
+ * the layout evql_plan_desc_t::row_filter_bits takes, valid until _destroy.
+ * Tables must be added in scan order.  arena_skiplist: one byte per row
+ * (PartitionArena::SkiplistReader::readNext), or NULL.
+ * An id that is not 20 bytes long fails with EVQL_ERUNTIME "invalid SHA1Hash"
+ * (util/SHA1.cc:79-85).
+ */
+typedef struct evql_lsm_chain evql_lsm_chain_t;
+int evql_lsm_chain_create(evql_ctx_t* ctx, evql_lsm_chain_t** out);
+void evql_lsm_chain_destroy(evql_lsm_chain_t* ch);
+int evql_lsm_chain_add(evql_lsm_chain_t* ch, evql_table_t* table,
+                       int has_skip_column, const uint8_t* arena_skiplist,
+                       uint64_t arena_skiplist_len);
+int evql_lsm_chain_build(evql_lsm_chain_t* ch);
+int evql_lsm_chain_filter(const evql_lsm_chain_t* ch, int idx,
+                          const uint8_t** bits, uint64_t* nrows,
+                          uint64_t* rows_kept);
+
+/* ------------------------------------------------------------------------ */
 /* build support                                                              */
 /* ------------------------------------------------------------------------ */
 /* Compile the fused kernel of `plan` for gfx950 without a device (used by

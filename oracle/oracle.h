@@ -88,6 +88,17 @@ uint64_t orc_result_rows_scanned(const orc_result_t* r);
 uint64_t orc_result_rows_passed(const orc_result_t* r);
 const char* orc_query_error(void);
 
+/* ---- lsm_oracle.c ---------------------------------------------------------- */
+/* PartitionCursor::openNextTable row filters (partition_cursor.cc:160-195):
+ * call once per table of the chain, newest first; filter_out receives one byte
+ * (0 dropped / 1 scanned) per row.  Returns 0, -1 on a read error, -2 for an id
+ * that is not 20 bytes ("invalid SHA1Hash"). */
+typedef struct orc_lsm orc_lsm_t;
+orc_lsm_t* orc_lsm_create(void);
+void orc_lsm_free(orc_lsm_t* m);
+int orc_lsm_next_table(orc_lsm_t* m, orc_table_t* t, int has_skip_column,
+                       const uint8_t* arena_skip, uint8_t* filter_out);
+
 /* GroupByMergeExpression (groupby.cc:528-672) over `nframes` partial-aggregate
  * frame payloads (varuint flags, varuint count, rows); only plan->select_exprs
  * is read.  orc_result_group_keys() returns the merged groups' SHA1 keys. */

@@ -345,6 +345,41 @@ def oracle_partial_frame(path_or_image, plan):
     return partial_frame(keys, r.columns[0])
 
 
+def oracle_lsm_filters(images, has_skip_column, arena_skips=None):
+    """PartitionCursor::openNextTable restatement over a newest-first chain of table
+    images: list of bool arrays (row scanned?)"""
+    import numpy as np
+    L = oracle()
+    L.orc_lsm_create.restype = C.c_void_p
+    L.orc_lsm_free.argtypes = [C.c_void_p]
+    L.orc_lsm_next_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p]
+    m = L.orc_lsm_create()
+    out = []
+    try:
+        for i, img in enumerate(images):
+            buf = bytes(img)
+            t = L.orc_table_open_image(buf, len(buf))
+            if not t:
+                raise IOError(L.orc_last_error().decode())
+            try:
+                n = L.orc_table_num_rows(t)
+                res = C.create_string_buffer(max(1, n))
+                sk = None
+                if arena_skips is not None and arena_skips[i] is not None:
+                    sk = np.ascontiguousarray(arena_skips[i], np.uint8).tobytes()
+                rc = L.orc_lsm_next_table(m, t, int(has_skip_column[i]), sk, res)
+                if rc == -2:
+                    raise RuntimeError("invalid SHA1Hash")
+                if rc:
+                    raise IOError("oracle lsm read error")
+                out.append(np.frombuffer(res.raw[:n], np.uint8).astype(bool))
+            finally:
+                L.orc_table_close(t)
+    finally:
+        L.orc_lsm_free(m)
+    return out
+
+
 def oracle_merge(plan, frames):
     """GroupByMergeExpression restatement over frame payloads"""
     L = oracle()
