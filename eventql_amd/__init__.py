@@ -97,6 +97,8 @@ def lib():
     L.evql_query_export_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
     L.evql_query_import_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.evql_query_reset.argtypes = [C.c_void_p]
+    L.evql_query_set_order.argtypes = [C.c_void_p, C.POINTER(K.SortSpec), C.c_uint32, C.c_int64,
+                                       C.c_uint64]
     L.evql_lsm_chain_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.evql_lsm_chain_destroy.argtypes = [C.c_void_p]
     L.evql_lsm_chain_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _u8p, C.c_uint64]
@@ -313,6 +315,12 @@ class Query:
         self.table = table
         self.plan = plan  # keeps the ctypes buffers alive
         self.h = h
+
+    def set_order(self, order):
+        """fuse ORDER BY .. LIMIT (eventql_amd.plan.Order) above the GROUP BY"""
+        self.order = order  # keeps the ctypes buffers alive
+        _check(lib().evql_query_set_order(self.h, order.specs, order.n, order.limit,
+                                          order.offset))
 
     def execute(self):
         _check(lib().evql_query_execute(self.h, None, None))

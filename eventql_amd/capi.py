@@ -138,6 +138,10 @@ class ColumnBuf(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_size_t)]
 
 
+class SortSpec(C.Structure):
+    _fields_ = [("expr", Program), ("descending", C.c_uint32)]
+
+
 class QueryStats(C.Structure):
     _fields_ = [
         ("rows_scanned", C.c_uint64),

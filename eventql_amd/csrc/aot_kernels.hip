@@ -290,6 +290,76 @@ __global__ void k_string_hash(const u8* image, const u64* pages, const u64* offs
   }
 }
 
+// ---- ORDER BY .. LIMIT ----------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_order_keys(OrderKeyArgs a) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = (const u64*) a.records + i * a.record_words;
+    u64 v = rec[a.word];
+    if (a.from_ident) {
+      // kind 2 = NULL key: payload 0 (the comparators ignore tags)
+      if (rec[0] == 2) v = 0;
+    } else if (a.count_word >= 0) {
+      const u64 cnt = rec[a.count_word];
+      if (cnt == 0) {
+        v = 0;
+      } else if (a.is_mean) {
+        v = evql_f64_bits(evql_as_f64(v) / (double) cnt);
+      }
+    }
+    u64 key;
+    if (a.type == 0) {
+      key = v;
+    } else if (a.type == 1) {
+      key = v ^ 0x8000000000000000ull;
+    } else {
+      if ((v << 1) == 0) v = 0;  // -0.0 == +0.0 for cmp_float64
+      key = (v >> 63) ? ~v : (v | 0x8000000000000000ull);
+    }
+    a.keys[i] = a.descending ? ~key : key;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_radix_hist(const u64* keys, u64 n, u64 hi_mask,
+                                                       u64 hi_value, u32 shift, u64* hist) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 k = keys[i];
+    if ((k & hi_mask) == hi_value) atomicAdd(&h[(k >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd((unsigned long long*) &hist[threadIdx.x], (unsigned long long) h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_order_collect(const u64* keys, u64 n, u64 threshold,
+                                                          u64 max_eq, u64* out_idx, u64* counters) {
+  // counters: [0] lt taken, [1] eq taken, [2] output cursor
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 k = keys[i];
+    bool take = k < threshold;
+    if (take) {
+      atomicAdd((unsigned long long*) &counters[0], 1ull);
+    } else if (k == threshold && *(volatile u64*) &counters[1] < max_eq) {
+      // (the plain read keeps millions of surplus ties off the atomic)
+      take = atomicAdd((unsigned long long*) &counters[1], 1ull) < max_eq;
+    }
+    if (take) out_idx[atomicAdd((unsigned long long*) &counters[2], 1ull)] = i;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_gather_records(const u64* records, u32 rw,
+                                                           const u64* idx, u64 m, u64* out) {
+  const u64 total = m * rw;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (u64) gridDim.x * blockDim.x) {
+    out[i] = records[idx[i / rw] * rw + i % rw];
+  }
+}
+
 // ---- LSM row filters ----------------------------------------------------------------
 // The reference walks the chain sequentially with a std::set of updated ids
 // (partition_cursor.cc:160-195): a row is dropped when it is skipped or when an
@@ -681,6 +751,37 @@ hipError_t launch_defined_from_levels(const uint8_t* dlevels, uint32_t dmax, uin
   if (ntiles == 0) return hipSuccess;
   hipLaunchKernelGGL(k_defined_from_levels, dim3((unsigned) ntiles), dim3(kBlock), 0, s, dlevels,
                      dmax, (u64) nslots, tags, (u64*) tile_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_order_keys(const OrderKeyArgs& a, hipStream_t s) {
+  if (a.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_order_keys, dim3(grid_for(a.n)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_radix_hist(const uint64_t* keys, uint64_t n, uint64_t hi_mask,
+                             uint64_t hi_value, uint32_t shift, uint64_t* hist, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_radix_hist, dim3(grid_for(n, kBlock, 1024)), dim3(kBlock), 0, s,
+                     (const u64*) keys, (u64) n, (u64) hi_mask, (u64) hi_value, shift, (u64*) hist);
+  return hipGetLastError();
+}
+
+hipError_t launch_order_collect(const uint64_t* keys, uint64_t n, uint64_t threshold,
+                                uint64_t max_eq, uint64_t* out_idx, uint64_t* counters,
+                                hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_order_collect, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) keys,
+                     (u64) n, (u64) threshold, (u64) max_eq, (u64*) out_idx, (u64*) counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_records(const uint64_t* records, uint32_t record_words,
+                                 const uint64_t* idx, uint64_t m, uint64_t* out, hipStream_t s) {
+  if (m == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_gather_records, dim3(grid_for(m * record_words)), dim3(kBlock), 0, s,
+                     (const u64*) records, record_words, (const u64*) idx, (u64) m, (u64*) out);
   return hipGetLastError();
 }
 

@@ -16,6 +16,8 @@ Status query_launch(evql_query* q);
 Status query_finish(evql_query* q);
 Status query_reset(evql_query* q);
 Status query_recount(evql_query* q);
+Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n, int64_t limit,
+                       uint64_t offset);
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows);
 }  // namespace evql
 
@@ -602,6 +604,14 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
 int evql_query_reset(evql_query_t* q) {
   API_TRY
   return ret(query_reset(q));
+  API_CATCH
+}
+
+int evql_query_set_order(evql_query_t* q, const evql_sort_spec_t* specs, uint32_t n_specs,
+                         int64_t limit, uint64_t offset) {
+  API_TRY
+  if (!q || (n_specs && !specs)) return fail(EVQL_EARG, "null argument");
+  return ret(query_set_order(q, specs, n_specs, limit, offset));
   API_CATCH
 }
 

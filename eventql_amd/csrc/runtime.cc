@@ -1085,12 +1085,66 @@ static Status fetch_results(evql_query* q) {
   HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (n > maxrec) n = maxrec;
-  q->ngroups = n;
-  q->records.assign(n * (nwords + 1), 0);
+  const uint64_t total_groups = n;
   if (n) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec), n * (nwords + 1) * 8));
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
     HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec, n, d_cnt, s));
+  }
+  // ORDER BY .. LIMIT: only the offset+limit smallest records by the first sort
+  // key (plus, with further sort keys, every tie of the boundary key) leave the
+  // device: radix select over the dense records, 8 bits per pass
+  const uint64_t want = q->offset + q->limit;
+  if (n && !q->order.empty() && q->has_limit && want < n) {
+    uint64_t m = 0;
+    if (want > 0) {
+      uint64_t *d_keys = nullptr, *d_hist = nullptr, *d_idx = nullptr, *d_ctr = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_keys), n * 8));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hist), 256 * 8));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), n * 8));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ctr), 3 * 8));
+      OrderKeyArgs ka = q->order_key;
+      ka.records = d_rec;
+      ka.record_words = nwords + 1;
+      ka.n = n;
+      ka.keys = d_keys;
+      HIP_TRY(launch_order_keys(ka, s));
+      uint64_t hi_mask = 0, hi_value = 0, remaining = want;
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        uint64_t hist[256];
+        HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(hist), s));
+        HIP_TRY(launch_radix_hist(d_keys, n, hi_mask, hi_value, uint32_t(shift), d_hist, s));
+        HIP_TRY(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        uint64_t d = 0;
+        while (d < 255 && hist[d] < remaining) remaining -= hist[d++];
+        hi_value |= d << shift;
+        hi_mask |= 0xFFull << shift;
+      }
+      // `remaining` = how many records with key == hi_value the result needs
+      const uint64_t max_eq = q->order.size() == 1 ? remaining : n;
+      uint64_t ctr[3] = {0, 0, 0};
+      HIP_TRY(hipMemsetAsync(d_ctr, 0, sizeof(ctr), s));
+      HIP_TRY(launch_order_collect(d_keys, n, hi_value, max_eq, d_idx, d_ctr, s));
+      HIP_TRY(hipMemcpyAsync(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      m = ctr[2];
+      uint64_t* d_rec2 = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec2), std::max<uint64_t>(m, 1) * (nwords + 1) * 8));
+      HIP_TRY(launch_gather_records(d_rec, nwords + 1, d_idx, m, d_rec2, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      hipFree(d_rec);
+      d_rec = d_rec2;
+      hipFree(d_keys);
+      hipFree(d_hist);
+      hipFree(d_idx);
+      hipFree(d_ctr);
+    }
+    n = m;
+  }
+  q->ngroups = n;
+  q->records.assign(n * (nwords + 1), 0);
+  if (n) {
     HIP_TRY(hipMemcpyAsync(q->records.data(), d_rec, n * (nwords + 1) * 8,
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1158,7 +1212,7 @@ static Status fetch_results(evql_query* q) {
   }
   if (d_rec) hipFree(d_rec);
   hipFree(d_cnt);
-  q->stats.num_groups = n;
+  q->stats.num_groups = total_groups;
   q->emit_pos = 0;
   q->executed = true;
   q->fetched = true;
@@ -1251,10 +1305,155 @@ static void save_state(const AggPlan& a, const uint64_t* st, std::vector<uint8_t
   }
 }
 
+// ---------------------------------------------------------------------------
+// ORDER BY .. LIMIT fused above the GROUP BY (orderby.cc:60-160, limit.cc:52-125)
+// ---------------------------------------------------------------------------
+Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n, int64_t limit,
+                       uint64_t offset) {
+  if (q->group_mode == EVQL_MODE_PARTIAL) {
+    return Status::error(EVQL_EARG, "ORDER BY / LIMIT above a partial aggregate");
+  }
+  if (n == 0 && limit < 0) {
+    return Status::error(EVQL_EARG, "can't execute ORDER BY: no sort specs");  // orderby.cc:53
+  }
+  std::vector<LoweredProgram> order(n);
+  std::vector<bool> desc(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    bool unsup = false;
+    std::string e = lower_program(specs[i].expr, &order[i], &unsup);
+    if (!e.empty()) return Status::error(unsup ? EVQL_ENOTSUP : EVQL_EARG, e);
+    if (order[i].is_aggregate) return Status::error(EVQL_EARG, "aggregate in ORDER BY");
+    std::vector<uint32_t> ins;
+    expr_inputs(order[i].call, &ins);
+    for (uint32_t in : ins) {
+      if (in >= q->select.size()) return Status::error(EVQL_EARG, "invalid input index");
+    }
+    switch (order[i].return_type) {  // there is no cmp#int64/bool;bool;
+      case EVQL_T_UINT64: case EVQL_T_INT64: case EVQL_T_FLOAT64: case EVQL_T_TIMESTAMP64:
+      case EVQL_T_STRING:
+        break;
+      default:
+        return Status::error(EVQL_EARG, "no comparator for the sort expression's type");
+    }
+    desc[i] = specs[i].descending != 0;
+  }
+  OrderKeyArgs ok{};
+  if (n > 0) {
+    const KernelPlan& kp = q->kp;
+    const ExprPtr& e0 = order[0].call;
+    if (e0->kind != Expr::INPUT) {
+      return Status::error(EVQL_ENOTSUP, "first sort expression is not a plain output column");
+    }
+    const uint32_t si = e0->input;
+    const LoweredProgram& sp = q->select[si];
+    auto type_code = [](uint32_t t) { return t == EVQL_T_INT64 ? 1u : (t == EVQL_T_FLOAT64 ? 2u : 0u); };
+    ok.count_word = -1;
+    ok.descending = desc[0];
+    if (q->select_passthrough[si] && sp.return_type != EVQL_T_STRING) {
+      ok.from_ident = 1;
+      ok.word = 1;
+      ok.type = type_code(sp.return_type);
+    } else if (sp.is_aggregate && sp.call->kind == Expr::AGG_GET) {
+      const AggPlan& a = kp.aggs[q->select_agg_index[si]];
+      ok.word = uint32_t(1 + kp.state_word_base() + a.first_word);
+      switch (a.fn) {
+        case EVQL_AGG_COUNT:
+        case EVQL_AGG_SUM_UINT64: ok.type = 0; break;
+        case EVQL_AGG_SUM_INT64: ok.type = 1; break;
+        case EVQL_AGG_SUM_FLOAT64: ok.type = 2; break;
+        case EVQL_AGG_MEAN_UINT64:
+        case EVQL_AGG_MEAN_INT64:
+        case EVQL_AGG_MEAN_FLOAT64:
+          ok.type = 2;
+          ok.is_mean = 1;
+          ok.count_word = int32_t(ok.word + 1);
+          break;
+        default:  // min / max
+          ok.type = type_code(sp.return_type);
+          ok.count_word = int32_t(ok.word + 1);
+      }
+    } else {
+      return Status::error(EVQL_ENOTSUP,
+                           "first sort expression cannot be read from a group record");
+    }
+  }
+  q->order.swap(order);
+  q->order_desc.swap(desc);
+  q->has_limit = limit >= 0;
+  q->limit = limit >= 0 ? uint64_t(limit) : 0;
+  q->offset = offset;
+  q->order_key = ok;
+  q->fetched = false;
+  return Status();
+}
+
+// cmp#int64/X;X; (boolean.cc:81-180): payloads only
+static int value_cmp(uint32_t type, const Value& a, const Value& b) {
+  switch (type) {
+    case EVQL_T_INT64: {
+      const int64_t l = int64_t(a.bits), r = int64_t(b.bits);
+      return l < r ? -1 : (l > r ? 1 : 0);
+    }
+    case EVQL_T_FLOAT64: {
+      double l, r;
+      memcpy(&l, &a.bits, 8);
+      memcpy(&r, &b.bits, 8);
+      return l < r ? -1 : (l > r ? 1 : 0);
+    }
+    case EVQL_T_STRING: {
+      const size_t m = std::min(a.str.size(), b.str.size());
+      const int c = m ? strncmp(a.str.data(), b.str.data(), m) : 0;
+      if (c != 0) return c < 0 ? -1 : 1;
+      return a.str.size() < b.str.size() ? -1 : (a.str.size() > b.str.size() ? 1 : 0);
+    }
+    default:
+      return a.bits < b.bits ? -1 : (a.bits > b.bits ? 1 : 0);
+  }
+}
+
+static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* outs);
+
+// orders the fetched records by every sort spec and applies OFFSET / LIMIT
+static Status order_fetched(evql_query* q) {
+  const uint64_t n = q->ngroups;
+  q->emit_order.clear();
+  if (q->order.empty() && !q->has_limit) return Status();
+  std::vector<uint64_t> idx(n);
+  for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+  if (!q->order.empty()) {
+    const size_t ns = q->order.size();
+    std::vector<Value> keys(n * ns), row;
+    for (uint64_t g = 0; g < n; ++g) {
+      Status st = final_row_values(q, g, &row);
+      if (!st.ok()) return st;
+      for (size_t j = 0; j < ns; ++j) {
+        std::string e = eval_expr(q->order[j].call, row, nullptr, &keys[g * ns + j]);
+        if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+      }
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
+      for (size_t j = 0; j < ns; ++j) {
+        const int c = value_cmp(q->order[j].return_type, keys[a * ns + j], keys[b * ns + j]);
+        if (c != 0) return q->order_desc[j] ? c > 0 : c < 0;
+      }
+      return false;
+    });
+  }
+  uint64_t lo = 0, hi = n;
+  if (q->has_limit) {
+    lo = std::min(q->offset, n);
+    hi = q->limit == 0 ? lo : std::min(n, q->offset + q->limit);
+  }
+  q->emit_order.assign(idx.begin() + lo, idx.begin() + hi);
+  return Status();
+}
+
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows) {
   if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
   if (!q->fetched) {
     Status st = fetch_results(q);
+    if (!st.ok()) return st;
+    st = order_fetched(q);
     if (!st.ok()) return st;
   }
   const KernelPlan& kp = q->kp;
@@ -1266,8 +1465,10 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
   const uint32_t nc = uint32_t(kp.cols.size());
   size_t emitted = 0;
   std::vector<Value> scan_vals(nc), sel_inputs(q->scan_select.size());
-  while (q->emit_pos < q->ngroups && emitted < max_rows) {
-    const uint64_t g = q->emit_pos;
+  const bool reordered = !q->order.empty() || q->has_limit;
+  const uint64_t emit_total = reordered ? q->emit_order.size() : q->ngroups;
+  while (q->emit_pos < emit_total && emitted < max_rows) {
+    const uint64_t g = reordered ? q->emit_order[q->emit_pos] : q->emit_pos;
     const uint64_t* rec = &q->records[g * rw];
     const uint64_t kind = rec[0], ident = rec[1];
     const uint64_t* st = rec + 1 + kp.state_word_base();
@@ -1374,6 +1575,76 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
     cols[i].size = q->out_cols[i].size();
   }
   *nrows = emitted;
+  return Status();
+}
+
+// the select-list values of fetched record g (EVQL_MODE_FINAL), as the emission
+// loop above computes them; ORDER BY evaluates its sort expressions over these
+static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* outs) {
+  const KernelPlan& kp = q->kp;
+  evql_table* t = q->table;
+  const size_t nsel = q->select.size();
+  const size_t rw = size_t(kp.words_per_slot()) + 1;
+  const uint32_t nc = uint32_t(kp.cols.size());
+  const uint64_t* rec = &q->records[g * rw];
+  const uint64_t kind = rec[0], ident = rec[1];
+  const uint64_t* st = rec + 1 + kp.state_word_base();
+  std::vector<Value> scan_vals(nc), sel_inputs(q->scan_select.size());
+  bool have_inputs = false;
+  if (kp.need_first_row) {
+    const uint64_t row = rec[1 + kp.first_row_word()];
+    for (uint32_t c = 0; c < nc; ++c) {
+      const ColAccess& ca = kp.cols[c];
+      Value v;
+      v.type = ca.stype;
+      v.tag = q->first_tags[uint64_t(c) * q->ngroups + g];
+      const uint64_t raw = q->first_vals[uint64_t(c) * q->ngroups + g];
+      if (ca.string_hash) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        v.tag = m.str_tag[row];
+        if (!v.tag) {
+          const ColumnLayout& cl = t->layout.columns[ca.layout_index];
+          v.str.resize(m.str_len[row]);
+          for (uint32_t k = 0; k < m.str_len[row]; ++k) {
+            const uint64_t pos = m.str_off[row] + k;
+            v.str[k] = char(t->host_image[cl.data_pages[pos >> 19].offset + (pos & 0x7ffff)]);
+          }
+        }
+      } else if (ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float) {
+        double d = double(raw);
+        memcpy(&v.bits, &d, 8);
+      } else if (ca.stype == EVQL_T_BOOL) {
+        v.bits = raw != 0;
+      } else {
+        v.bits = raw;
+      }
+      scan_vals[c] = v;
+    }
+    for (size_t j = 0; j < q->scan_select.size(); ++j) {
+      std::string e = eval_expr(q->scan_select[j].call, scan_vals, nullptr, &sel_inputs[j]);
+      if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+    }
+    have_inputs = true;
+  }
+  const std::vector<Value> none;
+  outs->assign(nsel, Value());
+  for (size_t i = 0; i < nsel; ++i) {
+    const LoweredProgram& lp = q->select[i];
+    Value& out = (*outs)[i];
+    if (lp.is_aggregate) {
+      Value av = agg_value(q, kp.aggs[q->select_agg_index[i]], st);
+      std::string e = eval_expr(lp.call, have_inputs ? sel_inputs : none, &av, &out);
+      if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+    } else if (q->select_passthrough[i]) {
+      out.type = lp.return_type;
+      out.bits = kind == 2 ? 0 : ident;
+      out.tag = kind == 2 ? uint8_t(EVQL_STAG_NULL) : uint8_t(0);
+    } else {
+      std::string e = eval_expr(lp.call, have_inputs ? sel_inputs : none, nullptr, &out);
+      if (!e.empty()) return Status::error(EVQL_ERUNTIME, e);
+    }
+    out.type = lp.return_type;
+  }
   return Status();
 }
 

@@ -150,6 +150,13 @@ struct evql_query {
   std::vector<uint8_t> first_tags;
   uint64_t emit_pos = 0;
   std::vector<std::vector<uint8_t>> out_cols;
+  // ORDER BY .. LIMIT fused above the GROUP BY (evql_query_set_order)
+  std::vector<evql::LoweredProgram> order;  // over the select list
+  std::vector<bool> order_desc;
+  bool has_limit = false;
+  uint64_t limit = 0, offset = 0;
+  evql::OrderKeyArgs order_key{};     // where the device finds sort key 0 in a record
+  std::vector<uint64_t> emit_order;  // record indices in output order (when ordered)
   evql_query_stats_t stats{};
   ~evql_query();
 };

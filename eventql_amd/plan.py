@@ -425,6 +425,35 @@ class Plan:
         return [p.return_type for p in self.scan_select]
 
 
+def out(i):
+    """output column i of a Plan, for ORDER BY expressions"""
+    return Col("$%d" % i)
+
+
+class Order:
+    """ORDER BY specs (+ LIMIT / OFFSET) over a Plan's output columns, lowered to
+    evql_sort_spec_t[] (OrderByExpression's sort_specs, orderby.cc:35-57).
+    specs: [(expr over out(i) | int column index, descending)]"""
+
+    def __init__(self, plan, specs=(), limit=None, offset=0):
+        types = plan.output_types
+        coltypes = {"$%d" % i: t for i, t in enumerate(types)}
+        colidx = {"$%d" % i: i for i in range(len(types))}
+        self.programs = []
+        self.descending = []
+        for e, desc in specs:
+            if isinstance(e, int):
+                e = out(e)
+            self.programs.append(CompiledProgram(e, coltypes, colidx))
+            self.descending.append(bool(desc))
+        n = len(self.programs)
+        self.specs = (K.SortSpec * max(1, n))(
+            *[K.SortSpec(p.struct, int(d)) for p, d in zip(self.programs, self.descending)])
+        self.n = n
+        self.limit = -1 if limit is None else int(limit)
+        self.offset = int(offset)
+
+
 # ---------------------------------------------------------------------------
 # decoding packed SVector bytes (sql/svalue.cc:410-517) into python values
 # ---------------------------------------------------------------------------

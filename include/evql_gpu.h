@@ -460,6 +460,32 @@ int evql_merge_next_batch(evql_merge_t* m, size_t max_rows,
                           evql_column_buf_t* cols, size_t* nrows);
 
 /* ------------------------------------------------------------------------ */
+/* ORDER BY .. LIMIT above the GROUP BY                                       */
+/*   OrderByExpression  sql/statements/select/orderby.cc:60-160               */
+/*   LimitExpression    sql/statements/select/limit.cc:52-125                 */
+/* ------------------------------------------------------------------------ */
+/*
+ * Fuses LimitExpression(limit, offset, OrderByExpression(specs, <this query>))
+ * into the operator so that a high-cardinality GROUP BY does not ship every
+ * group through nextBatch: the device selects the offset+limit smallest records
+ * by the first sort key (radix select over the group table), only those are
+ * fetched, and the host orders them by all specs.  Sort expressions are programs
+ * over the query's OUTPUT columns (X_INPUT i = select expression i), compared with
+ * the reference's cmp#int64/X;X; comparators: payloads only, NULL reads as 0, ties
+ * in unspecified order (the reference uses std::sort).  limit < 0: ORDER BY
+ * only.  limit == 0 yields no rows (limit.cc:58).  Call before execute().
+ * EVQL_ENOTSUP when the first sort expression is not a select column whose value
+ * the device can read from a group record (the group key, or a bare count / sum /
+ * min / max / mean): the caller then keeps the CPU operators above this one.
+ */
+typedef struct {
+  evql_program_t expr;
+  uint32_t descending;
+} evql_sort_spec_t;
+int evql_query_set_order(evql_query_t* q, const evql_sort_spec_t* specs,
+                         uint32_t n_specs, int64_t limit, uint64_t offset);
+
+/* ------------------------------------------------------------------------ */
 /* LSM row filters (PartitionCursor::openNextTable,                           */
 /* server/sql/partition_cursor.cc:83-226)                                     */
 /* ------------------------------------------------------------------------ */

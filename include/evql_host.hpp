@@ -150,6 +150,16 @@ class GpuGroupByScan : public TableExpression {
 
   evql_query_t* handle() { return query_; }
 
+  // Fuses LimitExpression(limit, offset, OrderByExpression(specs, this)) into the
+  // operator (orderby.cc:60-160, limit.cc:52-125); limit < 0 = ORDER BY only.
+  // Throws NotLowerable when the first sort key cannot be read on the device, in
+  // which case the scheduler stacks the CPU OrderBy / Limit operators on top.
+  void setOrder(const std::vector<evql_sort_spec_t>& specs, int64_t limit, uint64_t offset) {
+    int rc = evql_query_set_order(query_, specs.data(), uint32_t(specs.size()), limit, offset);
+    if (rc == EVQL_ENOTSUP) throw NotLowerable(evql_last_error());
+    if (rc != EVQL_OK) throw std::runtime_error(evql_last_error());
+  }
+
  private:
   static int heartbeat_thunk(void* self) {
     auto* s = static_cast<GpuGroupByScan*>(self);

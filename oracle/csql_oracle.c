@@ -1109,3 +1109,6 @@ const char* orc_query_error(void) { return g_qerr; }
 
 /* GroupByMergeExpression over partial-aggregate frames (kept separate too) */
 #include "csql_merge.inc"
+
+/* OrderByExpression + LimitExpression applied to a result */
+#include "csql_order.inc"

@@ -88,6 +88,12 @@ uint64_t orc_result_rows_scanned(const orc_result_t* r);
 uint64_t orc_result_rows_passed(const orc_result_t* r);
 const char* orc_query_error(void);
 
+/* OrderByExpression (orderby.cc:60-160) then LimitExpression (limit.cc:52-125)
+ * applied in place to a result; sort programs index the result's columns.
+ * limit < 0: no LIMIT.  Ties keep their input order.  Returns 0 / -1. */
+int orc_result_order_limit(orc_result_t* r, const evql_sort_spec_t* specs,
+                           uint32_t n_specs, int64_t limit, uint64_t offset);
+
 /* ---- lsm_oracle.c ---------------------------------------------------------- */
 /* PartitionCursor::openNextTable row filters (partition_cursor.cc:160-195):
  * call once per table of the chain, newest first; filter_out receives one byte

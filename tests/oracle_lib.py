@@ -281,7 +281,9 @@ class OracleResult:
         return list(zip(*self.columns)) if self.columns else []
 
 
-def oracle_run(path_or_image, plan):
+def oracle_run(path_or_image, plan, order=None):
+    """order: eventql_amd.plan.Order -> OrderByExpression + LimitExpression applied
+    to the operator's output (orc_result_order_limit)"""
     L = oracle()
     if isinstance(path_or_image, (bytes, bytearray, memoryview)):
         buf = bytes(path_or_image)
@@ -295,6 +297,12 @@ def oracle_run(path_or_image, plan):
         if not r:
             raise RuntimeError(L.orc_query_error().decode())
         try:
+            if order is not None:
+                L.orc_result_order_limit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
+                                                     C.c_int64, C.c_uint64]
+                if L.orc_result_order_limit(r, C.cast(order.specs, C.c_void_p), order.n,
+                                            order.limit, order.offset):
+                    raise RuntimeError(L.orc_query_error().decode())
             return _collect(L, r)
         finally:
             L.orc_result_free(r)

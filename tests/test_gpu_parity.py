@@ -351,6 +351,78 @@ def test_partial_rows_from_the_gpu_merge_to_the_final_result(mixed):
         m.close()
 
 
+def test_order_by_limit_above_the_group_by(mixed):
+    """OrderByExpression + LimitExpression fused into the operator
+    (evql_query_set_order): the device radix-selects the offset+limit records by the
+    first sort key, the host orders them; vs the oracle's OrderBy/Limit restatement"""
+    from eventql_amd.plan import Order, out
+    t, img, _ = mixed
+    k, a, v, nb, w = col("k"), col("a"), col("v"), col("nb"), col("w")
+    sel = [k, count(1), sum_(a), mean(v), min_(nb), max_(col("p"))]
+
+    def run(kw, specs, limit=None, offset=0, exact=True, keycols=None):
+        plan = Plan(T.MIXED_SCHEMA, **kw)
+        order = Order(plan, specs, limit=limit, offset=offset)
+        exp = O.oracle_run(img, plan, order=order)
+        q = t.query(plan)
+        q.set_order(order)
+        got = q.run()
+        assert got.nrows == exp.nrows, (got.nrows, exp.nrows)
+        assert q.stats()["num_groups"] == O.oracle_run(img, plan).nrows
+        if exact:   # total order: row by row, floats within 1e-6
+            for gr, er in zip(got.rows(), exp.rows()):
+                T.compare_results([gr], [er], exp.types, key_cols=1)
+        else:       # ties in unspecified order: the sort key columns agree row by row
+            for gr, er in zip(got.rows(), exp.rows()):
+                assert [gr[c] for c in keycols] == [er[c] for c in keycols]
+        q.close()
+        return got
+
+    g = dict(select=sel, group_by=[k])
+    got = run(g, [(2, True)], limit=10)                       # sum(a) desc
+    assert [r[2] for r in got.rows()] == sorted((r[2] for r in got.rows()), reverse=True)
+    run(g, [(1, False), (0, True)], limit=20, offset=5)       # count asc, k desc: total order
+    run(g, [(0, False)], limit=7)                             # the group key itself
+    run(g, [(0, True)], limit=7, offset=990)                  # runs off the end
+    run(g, [(3, True)], limit=3)                              # mean(v): float key
+    run(g, [(4, False), (0, False)], limit=15)                # min over a nullable: NULL reads 0
+    run(g, [(5, True), (0, False)], limit=4)                  # max over a UINT32_PLAIN column
+    run(g, [(1, True)], limit=25, exact=False, keycols=[1])   # ties at the cut
+    run(g, [(2, False), (0, False)])                          # ORDER BY without LIMIT
+    run(g, [(2, False)], limit=0)
+    run(g, [(2, False), (0, True)], limit=5000)               # limit > groups
+    run(g, [(0, False), (out(2) + out(1), True)], limit=9)    # expression as a later key
+    assert run(g, [], limit=13, exact=False, keycols=[]).nrows == 13   # LIMIT alone
+    run(dict(select=[count(1), sum_(a)]), [(0, False)], limit=1)       # no GROUP BY
+
+    # high cardinality: 65,536 and ~300,000 groups, 100 leave the device
+    hc = dict(select=[col("b"), count(1), sum_(a), max_(v)], group_by=[col("b")])
+    run(hc, [(2, True), (0, False)], limit=100)
+    run(hc, [(3, False), (0, False)], limit=100, offset=40000)
+    run(dict(select=[w, sum_(a)], group_by=[w], groups_hint=400000), [(1, True), (0, True)],
+        limit=50)
+    run(dict(select=[w, count(1)], group_by=[w], groups_hint=400000), [(1, True), (0, False)],
+        limit=50)                                             # all ties on key 0: full tie set
+
+    # first sort key not readable from a group record -> the CPU operators stay above
+    plan = Plan(T.MIXED_SCHEMA, **g)
+    for specs in ([(out(2) + out(1), True)], [(out(1) * 2, False)]):
+        q = t.query(plan)
+        with pytest.raises(E.EvqlError) as ei:
+            q.set_order(Order(plan, specs, limit=10))
+        assert ei.value.code == K.EVQL_ENOTSUP
+        q.close()
+    plan = Plan(T.MIXED_SCHEMA, select=[col("s"), count(1)], group_by=[col("s")])
+    q = t.query(plan)
+    with pytest.raises(E.EvqlError) as ei:
+        q.set_order(Order(plan, [(0, False)], limit=10))     # string key: identity is a hash
+    assert ei.value.code == K.EVQL_ENOTSUP
+    q.set_order(Order(plan, [(1, True), (0, False)], limit=10))   # .. but fine as 2nd key
+    exp = O.oracle_run(img, plan, order=Order(plan, [(1, True), (0, False)], limit=10))
+    assert q.run().rows() == exp.rows()
+    q.close()
+
+
 def test_nested_scan_known_answers(ctx):
     """Dremel flattening (CSTableScan, NO_AGGREGATION) on the device: the
     Runtime_test.cc:175-375 answers on the reference's fixture (re-encoded as

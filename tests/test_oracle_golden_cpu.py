@@ -249,6 +249,17 @@ def test_sql_00014_group_by_first_row(built, tmp_path):
     assert exp[0] == "city;customername"
     exp_rows = sorted(tuple(x.split(";")) for x in exp[1:] if x)
     assert got == exp_rows
+    # ... ORDER BY city: the golden file's row order pins the OrderByExpression /
+    # cmp_string restatement (and LIMIT / OFFSET slices of it)
+    from eventql_amd.plan import Order
+    in_file_order = [tuple(x.split(";")) for x in exp[1:] if x]
+    dec = lambda rows: [(a.decode(), b.decode()) for a, b in rows]
+    assert dec(O.oracle_run(img, plan, order=Order(plan, [(0, False)])).rows()) == in_file_order
+    assert dec(O.oracle_run(img, plan, order=Order(plan, [(0, True)])).rows()) == \
+        in_file_order[::-1]
+    assert dec(O.oracle_run(img, plan, order=Order(plan, [(0, False)], limit=5, offset=3)
+                            ).rows()) == in_file_order[3:8]
+    assert O.oracle_run(img, plan, order=Order(plan, [(0, False)], limit=0)).nrows == 0
 
 
 def test_v2_transcode_of_the_nested_fixture_keeps_the_known_answers(built):
