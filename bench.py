@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(QUERIES))
     ap.add_argument("--cpu-sample-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-bits", type=int, default=0,
+                    help="config2 run B (SURVEY.md 8d): k as UINT32_BITPACKED of this width")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +119,8 @@ def main():
     plan_fn = {"config2": B.config2, "config3": B.config3, "config5": config5_plan,
                "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw)}[args.workload]
     gen_kw = dict(u_mod=n_keys) if high_card else {}
+    if args.k_bits:
+        gen_kw["k_bits"] = args.k_bits
 
     ctx = E.Context(device)
     # every rank owns one partition; different seeds => different partitions
@@ -234,7 +238,9 @@ def main():
                 "query": query_text,
                 "rows_per_gpu": rows,
                 "columns": ncols,
-                "encodings": "UINT64_PLAIN/FLOAT_IEEE754",
+                "encodings": ("UINT64_PLAIN/FLOAT_IEEE754" if not args.k_bits else
+                              "k UINT32_BITPACKED(%d bit), others UINT64_PLAIN/FLOAT_IEEE754"
+                              % args.k_bits),
                 "groups": int(ngroups_out),
                 "partitions": world,
                 "merge": merge,

@@ -553,6 +553,7 @@ int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out) {
 int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_groups,
                              uint64_t* n_groups) {
   API_TRY
+  if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   hipStream_t s = q->ctx->stream;
   uint64_t* d_cnt = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d_cnt), 8) != hipSuccess) return fail(EVQL_ENOMEM, "hipMalloc");
@@ -573,6 +574,7 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
 
 int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n_groups) {
   API_TRY
+  if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   hipStream_t s = q->ctx->stream;
   for (int attempt = 0; attempt < 2; ++attempt) {
     MergeArgs a{};

@@ -34,7 +34,12 @@ struct AggPlan {
   ExprPtr arg;         // over scan columns; null for count
   int first_word = 0;  // index into state words
   int nwords = 0;
+  // count_distinct: index of the (group, value) pair set in EvqlArgs::pairset; the
+  // state word counts the pairs this aggregate inserted first
+  int distinct_index = -1;
 };
+
+static const int kMaxDistinct = 4;
 
 enum KeyMode {
   KEY_NONE = 0,    // no GROUP BY: one global group, register accumulators
@@ -51,6 +56,7 @@ struct KernelPlan {
   KeyMode key_mode = KEY_NONE;
   bool need_first_row = false;
   bool has_row_filter = false;
+  int n_distinct = 0;  // count_distinct aggregates (one HBM pair set each)
   // slot layout: word 0 identity, [second identity word], [first_row], states.
   // Hashed keys (several keys / strings) are identified by TWO independent
   // 64-bit hashes of the key tuple -- like the reference, which identifies a

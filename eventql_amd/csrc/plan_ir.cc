@@ -162,6 +162,9 @@ struct Decompiler {
               case EVQL_AGG_MAX_INT64:
                 e->type = EVQL_T_INT64;
                 break;
+              case EVQL_AGG_COUNT_DISTINCT_UINT64:
+                e->type = EVQL_T_UINT64;
+                break;
               case EVQL_AGG_SUM_FLOAT64:
               case EVQL_AGG_MIN_FLOAT64:
               case EVQL_AGG_MAX_FLOAT64:
@@ -231,7 +234,7 @@ std::string lower_program(const evql_program_t& p, LoweredProgram* out,
   out->is_aggregate = p.method_accumulate > 0;
   out->aggregate_fn = out->is_aggregate ? p.aggregate_fn : uint32_t(EVQL_AGG_NONE);
   if (out->is_aggregate && (p.aggregate_fn == EVQL_AGG_NONE ||
-                            p.aggregate_fn >= EVQL_AGG_COUNT_DISTINCT_UINT64)) {
+                            p.aggregate_fn > EVQL_AGG_COUNT_DISTINCT_UINT64)) {
     *unsupported = true;
     return "aggregate function not lowerable";
   }

@@ -314,6 +314,18 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
           kp.states.push_back({1});
           a.nwords = 1;
           break;
+        case EVQL_AGG_COUNT_DISTINCT_UINT64:
+          // aggregate.cc:77-137 (std::set per group): the state word counts the
+          // (group, value) pairs first inserted into the aggregate's HBM pair set.
+          // The sets themselves do not travel: no partial / merged execution.
+          if (plan->group_mode == EVQL_MODE_PARTIAL) {
+            return unsup("count_distinct in a partial aggregate is not lowered");
+          }
+          if (kp.n_distinct >= kMaxDistinct) return unsup("too many count_distinct aggregates");
+          a.distinct_index = kp.n_distinct++;
+          kp.states.push_back({0});
+          a.nwords = 1;
+          break;
         case EVQL_AGG_MIN_UINT64:
         case EVQL_AGG_MAX_UINT64:
         case EVQL_AGG_MIN_INT64:
@@ -382,7 +394,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     // rows); a workgroup whose table does thrash switches itself to the HBM
     // table (`bypass`).  Only far beyond the LDS capacity is the table skipped.
     const char* fp = getenv("EVQL_FORCE_PARTITIONED");
-    const bool part_ok = !(kp.key_mode == KEY_EXACT && expr_may_be_null(kp.group[0], kp.cols));
+    // (count_distinct inserts into its pair set from the row function, which the
+    // partition passes would run twice)
+    const bool part_ok = !(kp.key_mode == KEY_EXACT && expr_may_be_null(kp.group[0], kp.cols)) &&
+                         kp.n_distinct == 0;
     if ((hint > 8 * smax || (fp && atoi(fp) == 1)) && part_ok && !(fp && atoi(fp) == 0)) {
       // high cardinality: one random HBM atomic per state word per row tops out at
       // the chip's scattered-atomic rate (~2e10/s measured).  Instead the passing

@@ -235,6 +235,9 @@ evql_query::~evql_query() {
   if (d_gtab) hipFree(d_gtab);
   if (d_status) hipFree(d_status);
   if (d_counters) hipFree(d_counters);
+  for (auto* p : d_pairset) {
+    if (p) hipFree(p);
+  }
   if (d_row_filter) hipFree(d_row_filter);
   if (d_part_counts) hipFree(d_part_counts);
   if (d_bucket_start) hipFree(d_bucket_start);
@@ -888,6 +891,23 @@ Status query_launch(evql_query* q) {
       a.col[i].strpos = m.d_strpos;
     }
   }
+  if (kp.n_distinct > 0) {
+    // count_distinct pair sets: emptied before every launch
+    if (q->pairset_cap == 0) {
+      const uint64_t span = a.row_end > a.row_begin ? a.row_end - a.row_begin : 0;
+      uint64_t cap = 1 << 16;
+      while (cap < 2 * span && cap < (1ull << 22)) cap <<= 1;
+      q->pairset_cap = cap;
+    }
+    for (int i = 0; i < kp.n_distinct; ++i) {
+      if (!q->d_pairset[i]) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_pairset[i]), q->pairset_cap * 3 * 8));
+      }
+      HIP_TRY(hipMemsetAsync(q->d_pairset[i], 0xff, q->pairset_cap * 3 * 8, s));
+      a.pairset[i] = q->d_pairset[i];
+      a.pairset_cap[i] = q->pairset_cap;
+    }
+  }
   if (kp.partitioned && a.ntiles > 0) {
     // count -> per-bucket prefix -> scatter -> per-bucket LDS aggregation
     const uint64_t npart = 1ull << kp.part_bits;
@@ -965,10 +985,20 @@ Status query_finish(evql_query* q) {
     HIP_TRY(hipMemcpy(status, q->d_status, 16, hipMemcpyDeviceToHost));
     if (status[0] & 1u) return Status::error(EVQL_ERUNTIME, "division by zero");
     if (status[0] & 4u) return Status::error(EVQL_ERUNTIME, "modulo by zero");
-    if (status[0] & 2u) {
-      // group table too small: grow and run again
-      Status st = alloc_gtab(q, q->gcap * 4);
-      if (!st.ok()) return st;
+    if (status[0] & (2u | 8u)) {
+      // group table / count_distinct pair set too small: grow and run again
+      Status st;
+      if (status[0] & 2u) {
+        st = alloc_gtab(q, q->gcap * 4);
+        if (!st.ok()) return st;
+      }
+      if (status[0] & 8u) {
+        for (auto& p : q->d_pairset) {
+          if (p) hipFree(p);
+          p = nullptr;
+        }
+        q->pairset_cap *= 4;
+      }
       st = query_launch(q);
       if (!st.ok()) return st;
       continue;
@@ -1229,6 +1259,7 @@ static Value agg_value(const evql_query* q, const AggPlan& a, const uint64_t* st
   switch (a.fn) {
     case EVQL_AGG_COUNT:
     case EVQL_AGG_SUM_UINT64:
+    case EVQL_AGG_COUNT_DISTINCT_UINT64:
       v.type = EVQL_T_UINT64;
       v.bits = w0;
       break;

@@ -33,6 +33,8 @@ struct HostArgs {
   uint32_t* status;
   uint64_t* counters;
   HostColArg col[16];
+  uint64_t* pairset[4];
+  uint64_t pairset_cap[4];
 };
 
 struct Status {
@@ -138,6 +140,9 @@ struct evql_query {
   uint64_t gcap = 0;
   uint32_t* d_status = nullptr;
   uint64_t* d_counters = nullptr;
+  // count_distinct pair sets (3 word planes of pairset_cap slots each)
+  uint64_t* d_pairset[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t pairset_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool launched = false;
   bool executed = false;
