@@ -15,6 +15,8 @@
 // (evql_query_import_groups).
 #include <cstring>
 #include <map>
+#include <memory>
+#include <set>
 #include <unordered_map>
 #include "plan_ir.h"
 #include "runtime.h"
@@ -36,6 +38,7 @@ struct Cell {
   uint64_t w0 = 0;   // aggregate state / numeric SValue payload
   uint64_t cnt = 0;  // min / max / mean: non-null inputs seen
   std::string str;   // non-aggregate string payload
+  std::unique_ptr<std::set<uint64_t>> dset;  // count_distinct (aggregate.cc:77-80)
   uint8_t tag = 0;
   uint32_t type = EVQL_T_NIL;  // non-aggregates: decoded SType
 };
@@ -96,6 +99,12 @@ bool load_state(uint32_t fn, Reader* r, Cell* c) {
       if (b) memcpy(&c->w0, b, 8);
       return r->ok;
     }
+    case EVQL_AGG_COUNT_DISTINCT_UINT64: {  // aggregate.cc:119-125
+      const uint64_t n = r->varuint();
+      c->dset.reset(new std::set<uint64_t>());
+      for (uint64_t i = 0; i < n && r->ok; ++i) c->dset->insert(r->varuint());
+      return r->ok;
+    }
     default: {
       c->cnt = r->varuint();
       const uint8_t* b = r->bytes(8);
@@ -128,6 +137,12 @@ void merge_state(uint32_t fn, Cell* self, const Cell& o) {
     case EVQL_AGG_SUM_INT64:
       self->w0 += o.w0;
       return;
+    case EVQL_AGG_COUNT_DISTINCT_UINT64:  // aggregate.cc:103-109
+      if (o.dset) {
+        if (!self->dset) self->dset.reset(new std::set<uint64_t>());
+        self->dset->insert(o.dset->begin(), o.dset->end());
+      }
+      return;
     case EVQL_AGG_SUM_FLOAT64:
     case EVQL_AGG_MEAN_UINT64:
     case EVQL_AGG_MEAN_INT64:
@@ -157,6 +172,10 @@ Value state_value(uint32_t fn, const Cell& c) {
   switch (fn) {
     case EVQL_AGG_COUNT:
     case EVQL_AGG_SUM_UINT64: v.type = EVQL_T_UINT64; return v;
+    case EVQL_AGG_COUNT_DISTINCT_UINT64:
+      v.type = EVQL_T_UINT64;
+      v.bits = c.dset ? c.dset->size() : 0;
+      return v;
     case EVQL_AGG_SUM_INT64: v.type = EVQL_T_INT64; return v;
     case EVQL_AGG_SUM_FLOAT64: v.type = EVQL_T_FLOAT64; return v;
     case EVQL_AGG_MIN_UINT64:

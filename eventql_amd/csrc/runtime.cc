@@ -897,6 +897,10 @@ Status query_launch(evql_query* q) {
       const uint64_t span = a.row_end > a.row_begin ? a.row_end - a.row_begin : 0;
       uint64_t cap = 1 << 16;
       while (cap < 2 * span && cap < (1ull << 22)) cap <<= 1;
+      if (const char* e = getenv("EVQL_PAIRSET_CAP")) {  // tests: force the regrow path
+        cap = 64;
+        while (cap < uint64_t(atoll(e))) cap <<= 1;
+      }
       q->pairset_cap = cap;
     }
     for (int i = 0; i < kp.n_distinct; ++i) {

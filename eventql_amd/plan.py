@@ -137,6 +137,7 @@ def sum_(x): return Agg("sum", x)
 def min_(x): return Agg("min", x)
 def max_(x): return Agg("max", x)
 def mean(x): return Agg("mean", x)
+def count_distinct(x): return Agg("count_distinct", x)
 def col(name): return Col(name)
 def lit(v, t=None): return Lit(v, t)
 
@@ -222,6 +223,11 @@ def _resolve_types(e, coltypes):
             if at not in m:
                 raise CompileError("type error for mean")
             e.fn, e.rtype = m[at], K.T_FLOAT64
+        elif e.name == "count_distinct":
+            # count_distinct#uint64/uint64; (aggregate.cc:126-137)
+            if at != K.T_UINT64:
+                raise CompileError("type error for count_distinct")
+            e.fn, e.rtype = K.AGG_COUNT_DISTINCT_UINT64, K.T_UINT64
         else:
             raise CompileError("method not found: %s" % e.name)
         return e

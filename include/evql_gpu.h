@@ -154,7 +154,11 @@ typedef enum {
   EVQL_AGG_MEAN_UINT64 = 11, /* -> float64 */
   EVQL_AGG_MEAN_INT64 = 12,
   EVQL_AGG_MEAN_FLOAT64 = 13,
-  EVQL_AGG_COUNT_DISTINCT_UINT64 = 14 /* not lowerable: EVQL_ENOTSUP */
+  /* count_distinct#uint64/uint64; (aggregate.cc:77-137, std::set per group):
+   * exact, on one device (HBM set of (group, value) pairs); EVQL_ENOTSUP in
+   * EVQL_MODE_PARTIAL and for evql_query_export/import_groups -- the sets do not
+   * travel between devices.  evql_merge_* merges its wire states. */
+  EVQL_AGG_COUNT_DISTINCT_UINT64 = 14
 } evql_aggregate_fn;
 
 /* X_CALL_INSTANCE arg0 */

@@ -146,10 +146,74 @@ static void pop_str(vmstack_t* s, const uint8_t** p, uint32_t* len) {
 }
 
 /* ---- aggregate instances --------------------------------------------------- */
+/* count_distinct keeps a std::set<uint64_t> (aggregate.cc:77-80): a hash set
+ * here, sorted only when the state is saved */
+typedef struct {
+  uint64_t* v;
+  uint8_t* used;
+  size_t n, cap;
+} dset_t;
+
+static void dset_insert(dset_t* d, uint64_t x) {
+  if ((d->n + 1) * 2 > d->cap) {
+    size_t nc = d->cap ? d->cap * 2 : 16;
+    uint64_t* nv = (uint64_t*) calloc(nc, sizeof(uint64_t));
+    uint8_t* nu = (uint8_t*) calloc(nc, 1);
+    for (size_t i = 0; i < d->cap; ++i) {
+      if (!d->used[i]) continue;
+      size_t p = (size_t) ((d->v[i] * 0x9e3779b97f4a7c15ull) >> 17) & (nc - 1);
+      while (nu[p]) p = (p + 1) & (nc - 1);
+      nu[p] = 1;
+      nv[p] = d->v[i];
+    }
+    free(d->v);
+    free(d->used);
+    d->v = nv;
+    d->used = nu;
+    d->cap = nc;
+  }
+  size_t p = (size_t) ((x * 0x9e3779b97f4a7c15ull) >> 17) & (d->cap - 1);
+  while (d->used[p]) {
+    if (d->v[p] == x) return;
+    p = (p + 1) & (d->cap - 1);
+  }
+  d->used[p] = 1;
+  d->v[p] = x;
+  d->n++;
+}
+
+static int cmp_u64(const void* a, const void* b) {
+  uint64_t x = *(const uint64_t*) a, y = *(const uint64_t*) b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* the set's values in ascending order (std::set iteration); caller frees */
+static uint64_t* dset_sorted(const dset_t* d) {
+  uint64_t* out = (uint64_t*) malloc(sizeof(uint64_t) * (d && d->n ? d->n : 1));
+  size_t k = 0;
+  if (d) {
+    for (size_t i = 0; i < d->cap; ++i) {
+      if (d->used[i]) out[k++] = d->v[i];
+    }
+    qsort(out, k, sizeof(uint64_t), cmp_u64);
+  }
+  return out;
+}
+
 typedef struct {
   uint64_t w0; /* count / sum / min / max payload */
   uint64_t w1; /* non-null count for min/max/mean */
+  dset_t* ds;  /* count_distinct */
 } agg_t;
+
+static void agg_free(agg_t* a) {
+  if (a->ds) {
+    free(a->ds->v);
+    free(a->ds->used);
+    free(a->ds);
+    a->ds = NULL;
+  }
+}
 
 static __thread char g_qerr[256];
 
@@ -397,6 +461,12 @@ static int agg_accumulate(uint32_t fn, agg_t* a, vmstack_t* s) {
       memcpy(&a->w0, &cur, 8);
       return 0;
     }
+    case EVQL_AGG_COUNT_DISTINCT_UINT64: { /* aggregate.cc:82-85: insert popUInt64 */
+      uint64_t v = pop_u64(s, NULL);
+      if (!a->ds) a->ds = (dset_t*) calloc(1, sizeof(dset_t));
+      dset_insert(a->ds, v);
+      return 0;
+    }
     case EVQL_AGG_MIN_UINT64:
     case EVQL_AGG_MAX_UINT64: {
       uint64_t v = pop_u64(s, &tag);
@@ -466,6 +536,9 @@ static int agg_get(uint32_t fn, const agg_t* a, vmstack_t* s) {
     case EVQL_AGG_SUM_INT64:
     case EVQL_AGG_SUM_FLOAT64:
       push_tagged(s, a->w0, 0);
+      return 0;
+    case EVQL_AGG_COUNT_DISTINCT_UINT64: /* aggregate.cc:87-90: set size */
+      push_tagged(s, a->ds ? (uint64_t) a->ds->n : 0, 0);
       return 0;
     case EVQL_AGG_MIN_UINT64:
     case EVQL_AGG_MAX_UINT64:
@@ -842,6 +915,14 @@ static void agg_save(uint32_t fn, const agg_t* a, svec_t* v) {
     case EVQL_AGG_SUM_FLOAT64:
       sv_append(v, &a->w0, 8);
       return;
+    case EVQL_AGG_COUNT_DISTINCT_UINT64: { /* aggregate.cc:111-117: size, values ascending */
+      size_t n = a->ds ? a->ds->n : 0;
+      uint64_t* sorted = dset_sorted(a->ds);
+      sv_varuint(v, n);
+      for (size_t i = 0; i < n; ++i) sv_varuint(v, sorted[i]);
+      free(sorted);
+      return;
+    }
     default:
       sv_varuint(v, a->w1);
       sv_append(v, &a->w0, 8);
@@ -1067,7 +1148,10 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
     free(in);
   }
   for (size_t gi = 0; gi < map.n; ++gi) {
-    for (uint32_t e = 0; e < pl->n_select; ++e) free(map.g[gi].box[e]);
+    for (uint32_t e = 0; e < pl->n_select; ++e) {
+      free(map.g[gi].box[e]);
+      agg_free(&map.g[gi].inst[e]);
+    }
     free(map.g[gi].inst);
     free(map.g[gi].box);
     free(map.g[gi].boxlen);

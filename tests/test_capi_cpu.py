@@ -84,6 +84,12 @@ def test_compile_expression_coverage(built, tmp_path):
     # multi-column key (hashed identity), global aggregate, bit-packed + u32 columns
     plan = Plan(S, select=[k, b, count(1)], group_by=[k, b], groups_hint=100000)
     assert E.compile_only(plan, B.PLAIN_COLUMNS, cache_dir=str(tmp_path)) > 4000
+    # count_distinct (HBM pair set) under every key mode
+    cd = lambda x: Agg("count_distinct", x)
+    for kw in (dict(select=[k, cd(a), count(1), cd(b % 7)], group_by=[k]),
+               dict(select=[k, b, cd(a)], group_by=[k, b]),
+               dict(select=[cd(a + b)], where=a > 5)):
+        assert E.compile_only(Plan(S, **kw), B.PLAIN_COLUMNS, cache_dir=str(tmp_path)) > 4000
     plan = Plan(S, select=[count(1), sum_(a)], where=a < 100)
     cols = _cols("k", "a", "b", "v", a=dict(storage_type=K.ENC_UINT32_BITPACKED, bits=17),
                  b=dict(storage_type=K.ENC_UINT32_PLAIN))
@@ -112,10 +118,16 @@ def test_compile_string_predicates(built, tmp_path):
 
 def test_not_lowerable_plans_are_reported(built):
     S = dict(B.SCHEMA)
-    # count_distinct: lowerable set excludes it -> ENOTSUP
+    # count_distinct keeps its sets on one device: not in a partial aggregate
+    p = Plan(S, select=[col("k"), Agg("count_distinct", col("a"))], group_by=[col("k")],
+             mode=K.MODE_PARTIAL)
+    with pytest.raises(E.EvqlError) as ei:
+        E.compile_only(p, B.PLAIN_COLUMNS)
+    assert ei.value.code == K.EVQL_ENOTSUP
+    # an aggregate id outside the table
     p = Plan(S, select=[col("k"), count(1)], group_by=[col("k")])
-    p.select[1].struct.aggregate_fn = K.AGG_COUNT_DISTINCT_UINT64
-    p._select[1].aggregate_fn = K.AGG_COUNT_DISTINCT_UINT64
+    p.select[1].struct.aggregate_fn = 99
+    p._select[1].aggregate_fn = 99
     with pytest.raises(E.EvqlError) as ei:
         E.compile_only(p, B.PLAIN_COLUMNS)
     assert ei.value.code == K.EVQL_ENOTSUP

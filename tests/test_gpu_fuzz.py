@@ -72,6 +72,8 @@ class Gen:
             return Agg("count", Lit(1))
         if c < 0.3:
             return Agg("count", Col(r.choice(UINT_COLS + FLOAT_COLS)))
+        if c < 0.38:
+            return Agg("count_distinct", self.uint())
         if c < 0.6:
             return Agg("sum", self.uint())
         if c < 0.7:

@@ -351,6 +351,42 @@ def test_partial_rows_from_the_gpu_merge_to_the_final_result(mixed):
         m.close()
 
 
+def test_count_distinct(mixed, monkeypatch):
+    """count_distinct#uint64/uint64; (aggregate.cc:77-137): exact, through the HBM
+    pair set, under every key mode, next to other aggregates"""
+    from eventql_amd.plan import count_distinct as cd
+    t, img, _ = mixed
+    k, a, b, n, nb, w = col("k"), col("a"), col("b"), col("n"), col("nb"), col("w")
+    check(t, img, select=[k, cd(a), count(1), cd(b % 7), sum_(a)], group_by=[k])
+    check(t, img, select=[k, cd(nb), cd(n)], group_by=[k], where=W)     # NULL payloads read 0
+    check(t, img, key_cols=0, select=[cd(a), cd(k), cd(w), count(1)])   # no GROUP BY: 300k distinct w
+    check(t, img, key_cols=0, select=[cd(a)], where=a > 70000)          # no rows
+    check(t, img, select=[nb, cd(a)], group_by=[nb])                    # NULL key group
+    check(t, img, key_cols=2, select=[k, col("f"), cd(b)], group_by=[k, col("f")])   # hashed identity
+    check(t, img, select=[col("s"), cd(a % 100)], group_by=[col("s")])  # string key
+    check(t, img, select=[b, cd(k)], group_by=[b], groups_hint=70000)   # 65,536 groups
+    check(t, img, select=[k, cd(w) + count(1)], group_by=[k])           # post-aggregate arithmetic
+    # pair set smaller than the data: grown x4 and re-run
+    monkeypatch.setenv("EVQL_PAIRSET_CAP", "1024")
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(w)], group_by=[k], row_end=200_000))
+    exp = O.oracle_run(img, Plan(T.MIXED_SCHEMA, select=[k, cd(w)], group_by=[k], row_end=200_000))
+    T.compare_results(q.run().rows(), exp.rows(), exp.types)
+    q.close()
+    monkeypatch.delenv("EVQL_PAIRSET_CAP")
+    # the sets stay on one device
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(a)], group_by=[k]))
+    q.execute()
+    import torch
+    buf = torch.zeros(4096 * q.record_words(), dtype=torch.int64, device="cuda")
+    with pytest.raises(E.EvqlError) as ei:
+        q.export_groups(buf.data_ptr(), 4096)
+    assert ei.value.code == K.EVQL_ENOTSUP
+    q.close()
+    with pytest.raises(E.EvqlError) as ei:
+        t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(a)], group_by=[k], mode=K.MODE_PARTIAL))
+    assert ei.value.code == K.EVQL_ENOTSUP
+
+
 def test_order_by_limit_above_the_group_by(mixed):
     """OrderByExpression + LimitExpression fused into the operator
     (evql_query_set_order): the device radix-selects the offset+limit records by the

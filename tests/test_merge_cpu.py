@@ -7,7 +7,8 @@ import pytest
 
 import eventql_amd as E
 from eventql_amd import capi as K
-from eventql_amd.plan import Plan, Col, Lit, Call, If, count, sum_, min_, max_, mean
+from eventql_amd.plan import (Plan, Col, Lit, Call, If, count, sum_, min_, max_, mean,
+                              count_distinct)
 import oracle_lib as O
 import tables as T
 
@@ -75,6 +76,9 @@ def test_reference_verified_bytes(built):
     # first-row column: merged value = last frame's (see the next test), not the full scan's
     (dict(select=[col("k"), col("a"), count(1)], group_by=[col("k")]), 1, False),
     (dict(select=[count(1), sum_(col("a")) + count(1), max_(col("b"))]), 0, True),
+    # count_distinct states are value sets: the merge unions them
+    (dict(select=[col("k"), count_distinct(col("b") % 50), count_distinct(col("n"))],
+          group_by=[col("k")]), 1, True),
 ])
 def test_merge_of_row_range_partials(survey, kw, nkeys, full):
     got, exp_merge, exp_full = _merge(kw, survey)

@@ -170,6 +170,34 @@ def test_build_supplied_aggregates_vs_numpy(survey):
     assert r.rows() == [(None, None, 333334)]
 
 
+def test_count_distinct_vs_numpy(survey):
+    """count_distinct#uint64/uint64; (aggregate.cc:77-137): std::set semantics --
+    the payload counts regardless of the tag (NULL reads 0); saved state =
+    varuint size then the values ascending (:111-117)"""
+    from eventql_amd.plan import count_distinct
+    path, c = survey
+    r = run(path, select=[col("k"), count_distinct(col("a")), count_distinct(col("n")),
+                          count_distinct(col("b") % 7), count(1)], group_by=[col("k")])
+    k = c["k"]
+    n0 = np.where(c["n_present"] == 1, c["n"], 0)
+    for row in r.rows():
+        m = k == row[0]
+        assert row[1] == len(np.unique(c["a"][m]))
+        assert row[2] == len(np.unique(n0[m]))
+        assert row[3] == len(np.unique(c["b"][m] % np.uint64(7)))
+    r = run(path, select=[count_distinct(col("a")), count_distinct(col("k"))],
+            where=col("a") > 30000)
+    m = c["a"] > 30000
+    assert r.rows() == [(len(np.unique(c["a"][m])), len(np.unique(c["k"][m])))]
+    # wire state
+    r = run(path, select=[col("k"), count_distinct(col("b") % 5)], group_by=[col("k")],
+            mode=K.MODE_PARTIAL, where=col("k") < 2)
+    for data in r.columns[0]:
+        kk = int.from_bytes(data[2:10], "little")
+        vals = sorted(set((c["b"][k == kk] % np.uint64(5)).tolist()))
+        assert data[11:] == bytes([len(vals)] + vals)
+
+
 # ---- the reference's own fixtures ----------------------------------------------------
 TESTTBL = os.path.join(T.GOLDEN, "testtbl.cst")
 NESTED_SCHEMA = {
