@@ -163,9 +163,9 @@ def main():
             # partial aggregates -> dense records -> every rank -> merge kernel
             n = q.export_groups(send.data_ptr(), max_groups)
             parts = D.exchange_all_gather(send, n, rw, max_groups)
-            for r, (t, cnt) in enumerate(parts):
-                if r != rank and cnt:
-                    q.import_groups(t.contiguous().data_ptr(), cnt)
+            foreign, cnt = D.gather_foreign(parts, rank, rw)
+            if cnt:
+                q.import_groups(foreign.data_ptr(), cnt)
             return drain(q)
         # high cardinality: hash-partitioned all-to-all, each rank merges its range
         n = q.export_groups(send.data_ptr(), n_keys + 16)

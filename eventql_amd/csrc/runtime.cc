@@ -1020,8 +1020,8 @@ Status query_finish(evql_query* q) {
     // when the first nextBatch asks for them (a partial aggregate that is merged
     // on the device never leaves it).  Only the group count is read back.
     {
-      uint64_t* d_cnt = nullptr;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), 8));
+      // (counter word 4 of the per-query counter block: no allocation per step)
+      uint64_t* d_cnt = q->d_counters + 4;
       HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
       HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8,
                                    uint32_t(q->kp.words_per_slot()), nullptr, 0, d_cnt,
@@ -1029,7 +1029,6 @@ Status query_finish(evql_query* q) {
       uint64_t n = 0;
       HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
-      hipFree(d_cnt);
       q->ngroups = n;
       q->stats.num_groups = n;
     }
@@ -1045,15 +1044,13 @@ Status query_finish(evql_query* q) {
 // (import of another partition's groups)
 Status query_recount(evql_query* q) {
   evql_ctx* ctx = q->ctx;
-  uint64_t* d_cnt = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), 8));
+  uint64_t* d_cnt = q->d_counters + 4;
   HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
   HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, uint32_t(q->kp.words_per_slot()),
                                nullptr, 0, d_cnt, ctx->stream));
   uint64_t n = 0;
   HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  hipFree(d_cnt);
   q->ngroups = n;
   q->stats.num_groups = n;
   q->fetched = false;
@@ -1109,15 +1106,10 @@ static Status fetch_results(evql_query* q) {
   const uint64_t stride = q->gcap + 8;
   const uint64_t maxrec = q->gcap + 2;
   uint64_t* d_rec = nullptr;
-  uint64_t* d_cnt = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), 8));
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
-  // first pass only counts (max_records = 0) so that the record buffer is sized
-  // by the number of groups, not by the table capacity
-  HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, nullptr, 0, d_cnt, s));
-  uint64_t n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  uint64_t* d_cnt = q->d_counters + 5;
+  // the record buffer is sized by the number of groups (counted by finish /
+  // recount / reset), not by the table capacity
+  uint64_t n = q->stats.num_groups;
   if (n > maxrec) n = maxrec;
   const uint64_t total_groups = n;
   if (n) {
@@ -1245,7 +1237,6 @@ static Status fetch_results(evql_query* q) {
     hipFree(d_tags);
   }
   if (d_rec) hipFree(d_rec);
-  hipFree(d_cnt);
   q->stats.num_groups = total_groups;
   q->emit_pos = 0;
   q->executed = true;

@@ -54,10 +54,24 @@ def exchange_all_gather(records, n, record_words, max_groups, group=None):
         recv = torch.cat(parts)
     out = []
     recv = recv.view(world, width)
+    counts = recv[:, 0].tolist()  # one device->host sync for all ranks
     for r in range(world):
-        cnt = int(recv[r, 0].item())
+        cnt = int(counts[r])
         out.append((recv[r, 1:1 + cnt * record_words], cnt))
     return out
+
+
+def gather_foreign(parts, rank, record_words):
+    """the other ranks' records of an exchange_all_gather as ONE contiguous tensor
+    (a single merge launch instead of one per rank); (tensor | None, count)"""
+    others = [t for r, (t, c) in enumerate(parts) if r != rank and c]
+    if not others:
+        return None, 0
+    cat = others[0].contiguous() if len(others) == 1 else torch.cat(others)
+    if cat.device.type == "cuda":
+        # the merge kernel runs on the library's own stream
+        torch.cuda.current_stream(cat.device).synchronize()
+    return cat, cat.numel() // record_words
 
 
 def bucket_by_owner(records, n, record_words, world):

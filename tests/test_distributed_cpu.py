@@ -117,7 +117,11 @@ def _worker(rank, world, port, n_parts, rows, key, mode, q):
         t = torch.from_numpy(dense.reshape(-1).copy())
         if mode == "all_gather":
             parts = D.exchange_all_gather(t, len(local), RW, max_groups=8192)
-            merged = _merge([p.numpy().reshape(c, RW) for p, c in parts])
+            # own records + everybody else's as one contiguous block (what bench.py
+            # hands to evql_query_import_groups)
+            foreign, cnt = D.gather_foreign(parts, rank, RW)
+            assert cnt == sum(c for r, (_, c) in enumerate(parts) if r != rank)
+            merged = _merge([dense] + ([foreign.numpy().reshape(cnt, RW)] if cnt else []))
             q.put((rank, merged))
         else:
             recv, cnt = D.exchange_all_to_all(t, len(local), RW)
