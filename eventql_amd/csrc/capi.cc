@@ -555,8 +555,8 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
   API_TRY
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   hipStream_t s = q->ctx->stream;
-  uint64_t* d_cnt = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&d_cnt), 8) != hipSuccess) return fail(EVQL_ENOMEM, "hipMalloc");
+  if (!q->d_gtab || !q->d_counters) return fail(EVQL_EARG, "execute() was not called");
+  uint64_t* d_cnt = q->d_counters + 6;  // per-query counter block: no allocation per call
   hipMemsetAsync(d_cnt, 0, 8, s);
   hipError_t e = launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8,
                                       uint32_t(q->kp.words_per_slot()),
@@ -564,7 +564,6 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
   uint64_t n = 0;
   hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s);
   hipError_t e2 = hipStreamSynchronize(s);
-  hipFree(d_cnt);
   if (e != hipSuccess || e2 != hipSuccess) return fail(EVQL_EDEVICE, "export kernel failed");
   if (n > max_groups) return fail(EVQL_ENOMEM, "export buffer too small");
   *n_groups = n;

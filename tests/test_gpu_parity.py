@@ -351,6 +351,38 @@ def test_partial_rows_from_the_gpu_merge_to_the_final_result(mixed):
         m.close()
 
 
+@pytest.mark.parametrize("bits", [1, 2, 3, 4, 5, 7, 8, 9, 11, 13, 16, 17, 21, 24, 27, 31, 32])
+def test_every_bit_width_in_the_fused_kernel(ctx, bits):
+    """UINT32_BITPACKED pages of every width class (word-aligned, straddling, full)
+    read by the pairwise in-kernel decoder (evql_bitpacked_x2) as key, predicate
+    operand and aggregate argument; 300,001 rows = several blocks past a page"""
+    n = 300_001
+    rng = np.random.default_rng(bits)
+    maxv = (1 << bits) - 1
+    x = rng.integers(0, maxv + 1, n, dtype=np.uint64)
+    y = rng.integers(0, maxv + 1, n, dtype=np.uint64)
+    w = E.Writer([dict(name="x", logical_type=K.COL_UNSIGNED_INT,
+                       storage_type=K.ENC_UINT32_BITPACKED, bitpack_max_value=maxv),
+                  dict(name="y", logical_type=K.COL_UNSIGNED_INT,
+                       storage_type=K.ENC_UINT32_BITPACKED, bitpack_max_value=maxv)])
+    w.put("x", x)
+    w.put("y", y)
+    w.commit(n)
+    img = w.image()
+    w.close()
+    t = ctx.open_image(img)
+    S = dict(x=K.T_UINT64, y=K.T_UINT64)
+    plan = Plan(S, select=[col("x") % 13, count(1), sum_(col("y")), max_(col("x"))],
+                group_by=[col("x") % 13], where=col("y") >= (maxv // 3))
+    exp = O.oracle_run(img, plan)
+    q = t.query(plan)
+    T.compare_results(q.run().rows(), exp.rows(), exp.types)
+    q.close()
+    got = t.query(Plan(S, select=[sum_(col("x")), sum_(col("y"))])).run().rows()
+    assert got == [(int(x.sum()), int(y.sum()))]
+    t.close()
+
+
 def test_count_distinct(mixed, monkeypatch):
     """count_distinct#uint64/uint64; (aggregate.cc:77-137): exact, through the HBM
     pair set, under every key mode, next to other aggregates"""
