@@ -127,6 +127,17 @@ __device__ __forceinline__ void evql_soa_x2(const u64* soa, u64 r, u64& v0, u64&
 // block of 128 values = 16*B bytes; value i7: lane l = i7 & 3, k = i7 >> 2,
 // bit position p = k*B inside the lane stream; lane word w sits at u32 index
 // 4*w + l.  The first page carries a 4-byte max_value header.
+// Hides the value range of a decoded bit-packed value from the optimizer.  With
+// the range known (<= 24 bits) a following `x % 13` was narrowed to the 24-bit
+// float-reciprocal division and came out one too high in the quotient for
+// x >= 1.36e7, x = 12 (mod 13) -- remainder "-1" (observed on the 24-bit column of
+// tests/test_gpu_parity.py::test_every_bit_width_in_the_fused_kernel).  Plain
+// columns never take that path; neither do these after the barrier.
+__device__ __forceinline__ u32 evql_opaque(u32 v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <int B>
 __device__ __forceinline__ u32 evql_bitpacked(const u8* image, const u64* pages, u64 i) {
   if (B == 0) return 0;
@@ -138,7 +149,7 @@ __device__ __forceinline__ u32 evql_bitpacked(const u8* image, const u64* pages,
   const u32* W = reinterpret_cast<const u32*>(base);
   u64 v = (u64) W[4 * w + l] >> s;
   if (s + B > 32) v |= (u64) W[4 * (w + 1) + l] << (32 - s);
-  return (u32) (v & (B >= 32 ? 0xffffffffull : ((1ull << (B & 31)) - 1)));
+  return evql_opaque((u32) (v & (B >= 32 ? 0xffffffffull : ((1ull << (B & 31)) - 1))));
 }
 
 // values i (even) and i + 1: adjacent lanes of the same lane word, so one address
@@ -175,8 +186,8 @@ __device__ __forceinline__ void evql_bitpacked_x2(const u8* image, const u64* pa
     v1 = __funnelshift_r(lo.y, hi.y, s);
   }
   const u32 m = B >= 32 ? 0xffffffffu : ((1u << (B & 31)) - 1u);
-  a = v0 & m;
-  b = v1 & m;
+  a = evql_opaque(v0 & m);
+  b = evql_opaque(v1 & m);
 }
 
 // runtime-width variant (decode kernels)
@@ -191,7 +202,7 @@ __device__ __forceinline__ u32 evql_bitpacked_rt(const u8* image, const u64* pag
   const u32* W = reinterpret_cast<const u32*>(base);
   u64 v = (u64) W[4 * w + l] >> s;
   if (s + B > 32) v |= (u64) W[4 * (w + 1) + l] << (32 - s);
-  return (u32) (v & (B >= 32 ? 0xffffffffull : ((1ull << B) - 1)));
+  return evql_opaque((u32) (v & (B >= 32 ? 0xffffffffull : ((1ull << B) - 1))));
 }
 
 __device__ __forceinline__ bool evql_row_filter(const u8* bits, u64 len, u64 row) {
