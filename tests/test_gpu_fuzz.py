@@ -1,8 +1,13 @@
-"""Randomised differential test: random predicates / keys / aggregates over the
-mixed-encoding table, HIP path vs oracle.  Seeds are fixed, so failures are
-reproducible (`-k "seed3"`)."""
+"""Randomised differential tests: random predicates / keys / aggregates, HIP path
+vs oracle.  Seeds are fixed, so failures are reproducible (`-k "seed3"`).
+
+Two tables: the mixed-encoding table of the parity tests, and a table whose
+bit-packed / plain / LEB128 columns span their full value ranges (values next to
+2^17, 2^24, 2^31, 2^32, 2^64), where range-dependent code generation (narrowed
+division, shifts, wrap-around) shows."""
 import random
 
+import numpy as np
 import pytest
 
 import eventql_amd as E
@@ -13,22 +18,20 @@ import tables as T
 
 pytestmark = pytest.mark.gpu
 
-UINT_COLS = ["k", "a", "b", "n", "p", "k10", "nb", "w"]
-FLOAT_COLS = ["v", "nv"]
-BOOL_COLS = ["f"]
-
 
 class Gen:
-    def __init__(self, seed):
+    def __init__(self, seed, uint_cols, float_cols, bool_cols, key_cols, first_cols, lits):
         self.r = random.Random(seed)
+        self.uint_cols, self.float_cols, self.bool_cols = uint_cols, float_cols, bool_cols
+        self.key_cols, self.first_cols, self.lits = key_cols, first_cols, lits
 
     def uint(self, depth=0):
         r = self.r
         c = r.random()
         if depth > 2 or c < 0.35:
-            return Col(r.choice(UINT_COLS))
+            return Col(r.choice(self.uint_cols))
         if c < 0.5:
-            return Lit(r.choice([0, 1, 2, 7, 1000, 30000, 65535, 1 << 40]))
+            return Lit(r.choice(self.lits))
         if c < 0.9:
             op = r.choice(["add", "sub", "mul", "div", "mod"])
             rhs = self.uint(depth + 1)
@@ -41,7 +44,7 @@ class Gen:
         r = self.r
         c = r.random()
         if depth > 2 or c < 0.4:
-            return Col(r.choice(FLOAT_COLS))
+            return Col(r.choice(self.float_cols))
         if c < 0.55:
             return Lit(r.choice([0.0, 1.5, -2.25, 100.0, 8000.5]))
         if c < 0.92:
@@ -58,8 +61,8 @@ class Gen:
                             self.uint(depth + 1), self.uint(depth + 1))
             return Call(r.choice(["lt", "gt", "lte", "gte"]), self.flt(depth + 1),
                         self.flt(depth + 1))
-        if c < 0.55:
-            return Col("f")
+        if c < 0.55 and self.bool_cols:
+            return Col(r.choice(self.bool_cols))
         if c < 0.65:
             return Call("neg", self.boolean(depth + 1))
         return Call(r.choice(["logical_and", "logical_or"]), self.boolean(depth + 1),
@@ -71,7 +74,7 @@ class Gen:
         if c < 0.2:
             return Agg("count", Lit(1))
         if c < 0.3:
-            return Agg("count", Col(r.choice(UINT_COLS + FLOAT_COLS)))
+            return Agg("count", Col(r.choice(self.uint_cols + self.float_cols)))
         if c < 0.38:
             return Agg("count_distinct", self.uint())
         if c < 0.6:
@@ -82,47 +85,34 @@ class Gen:
             return Agg(r.choice(["min", "max"]), r.choice([self.uint(), self.flt()]))
         return Agg("mean", r.choice([self.uint(), self.flt()]))
 
-    def plan_kwargs(self):
+    def plan_kwargs(self, row_ends):
         r = self.r
         nkeys = r.choice([0, 1, 1, 1, 2])
         keys = []
         for _ in range(nkeys):
             c = r.random()
             if c < 0.6:
-                keys.append(Col(r.choice(["k", "k10", "f", "nb", "n", "s", "ns", "b"])))
+                keys.append(Col(r.choice(self.key_cols)))
             elif c < 0.8:
-                keys.append(Call("mod", self.uint(1), Lit(r.choice([3, 17, 1000]))))
+                keys.append(Call("mod", self.uint(1), Lit(r.choice([3, 13, 17, 1000]))))
             else:
                 keys.append(self.boolean(1))
         select = list(keys) + [self.aggregate() for _ in range(r.randint(1, 4))]
         if keys and r.random() < 0.3:
-            select.insert(len(keys), Col(r.choice(["a", "v", "s"])))  # first-row value
+            select.insert(len(keys), Col(r.choice(self.first_cols)))  # first-row value
         kw = dict(select=select, group_by=keys)
         if r.random() < 0.7:
             kw["where"] = self.boolean()
         if r.random() < 0.2:
-            kw["row_end"] = r.choice([1, 4097, 131073, 250000])
+            kw["row_end"] = r.choice(row_ends)
         kw["groups_hint"] = r.choice([0, 0, 10, 1000, 100000])
-        return kw, len(keys) + (1 if len(select) > len(keys) and isinstance(select[len(keys)], Col)
-                                and keys else 0)
+        return kw
 
 
-@pytest.fixture(scope="module")
-def mixed(ctx):
-    img, _ = T.mixed_table(300_000)
-    t = ctx.open_image(img)
-    yield t, img
-    t.close()
-
-
-@pytest.mark.parametrize("seed", range(40))
-def test_random_plan(mixed, seed):
-    t, img = mixed
-    g = Gen(seed)
-    kw, _ = g.plan_kwargs()
+def run_case(t, img, schema, kw):
     nkeys = len(kw["group_by"])
     try:
-        plan = Plan(T.MIXED_SCHEMA, **kw)
+        plan = Plan(schema, **kw)
     except CompileError:
         pytest.skip("type error in the generated expression")
     try:
@@ -149,3 +139,82 @@ def test_random_plan(mixed, seed):
                           abs_tol=1e-3)
     finally:
         q.close()
+
+
+# ---- the mixed-encoding table -----------------------------------------------------------
+MIXED = dict(uint_cols=["k", "a", "b", "n", "p", "k10", "nb", "w"], float_cols=["v", "nv"],
+             bool_cols=["f"], key_cols=["k", "k10", "f", "nb", "n", "s", "ns", "b"],
+             first_cols=["a", "v", "s"], lits=[0, 1, 2, 7, 1000, 30000, 65535, 1 << 40])
+
+
+@pytest.fixture(scope="module")
+def mixed(ctx):
+    img, _ = T.mixed_table(300_000)
+    t = ctx.open_image(img)
+    yield t, img
+    t.close()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_plan(mixed, seed):
+    t, img = mixed
+    kw = Gen(seed, **MIXED).plan_kwargs([1, 4097, 131073, 250000])
+    run_case(t, img, T.MIXED_SCHEMA, kw)
+
+
+# ---- full-range columns -------------------------------------------------------------------
+RANGES_SCHEMA = dict(x17=K.T_UINT64, x24=K.T_UINT64, x31=K.T_UINT64, x32=K.T_UINT64,
+                     p32=K.T_UINT64, q64=K.T_UINT64, l64=K.T_UINT64, g=K.T_UINT64,
+                     fv=K.T_FLOAT64, nx24=K.T_UINT64)
+RANGES = dict(uint_cols=["x17", "x24", "x31", "x32", "p32", "q64", "l64", "g", "nx24"],
+              float_cols=["fv"], bool_cols=[], key_cols=["g", "x17", "nx24"],
+              first_cols=["x24", "q64", "fv"],
+              lits=[1, 3, 13, 255, 65536, (1 << 24) - 1, (1 << 31) + 5, (1 << 32) - 1, 1 << 63])
+
+
+def ranges_table(n=200_000):
+    rng = np.random.default_rng(77)
+
+    def edgy(bits):
+        # uniform, plus a third of the rows within 40 of the top of the range
+        top = (1 << bits) - 1
+        v = rng.integers(0, top, n, dtype=np.uint64, endpoint=True)
+        near = np.uint64(top) - rng.integers(0, 40, n, dtype=np.uint64)
+        return np.where(rng.random(n) < 0.33, near, v).astype(np.uint64)
+
+    c = dict(x17=edgy(17), x24=edgy(24), x31=edgy(31), x32=edgy(32), p32=edgy(32),
+             q64=edgy(64), l64=edgy(64), g=rng.integers(0, 37, n, dtype=np.uint64),
+             fv=rng.normal(0, 1e6, n), nx24=edgy(24))
+    pres = (rng.random(n) < 0.8).astype(np.uint8)
+    bp = lambda name, bits, **kw: dict(name=name, logical_type=K.COL_UNSIGNED_INT,
+                                       storage_type=K.ENC_UINT32_BITPACKED,
+                                       bitpack_max_value=(1 << bits) - 1, **kw)
+    w = E.Writer([bp("x17", 17), bp("x24", 24), bp("x31", 31), bp("x32", 32),
+                  dict(name="p32", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT32_PLAIN),
+                  dict(name="q64", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+                  dict(name="l64", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_LEB128),
+                  bp("g", 6),
+                  dict(name="fv", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754),
+                  bp("nx24", 24, dlevel_max=1)])
+    for name in ("x17", "x24", "x31", "x32", "p32", "q64", "l64", "g", "fv"):
+        w.put(name, c[name])
+    w.put("nx24", c["nx24"], present=pres)
+    w.commit(n)
+    img = w.image()
+    w.close()
+    return img
+
+
+@pytest.fixture(scope="module")
+def ranges(ctx):
+    img = ranges_table()
+    t = ctx.open_image(img)
+    yield t, img
+    t.close()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_plan_full_range_columns(ranges, seed):
+    t, img = ranges
+    kw = Gen(1000 + seed, **RANGES).plan_kwargs([1, 4097, 131073, 150000])
+    run_case(t, img, RANGES_SCHEMA, kw)
