@@ -67,11 +67,20 @@ def cpu_baseline(ctx, plan_fn, columns, sample_rows, **gen_kw):
     t0 = time.time()
     res = O.oracle_run(path, plan)
     dt = time.time() - t0
+    out = dict(value=sample_rows / dt, unit="rows/s", cores=1, kind="port",
+               sample="%d-row instance of the same table/query, oracle (C restatement of "
+                      "FastCSTableScan+VM+GroupBy), %d groups, %.1f s"
+                      % (sample_rows, res.nrows, dt))
+    # the reference runs one thread per partition (one partition per connection):
+    # the same sample as T concurrent partitions on the host's cores, for scale
+    T = max(1, min(16, len(os.sched_getaffinity(0))))
+    if T > 1:
+        dtp = O.oracle_time_parallel(path, [plan_fn() for _ in range(T)])
+        out["all_cores"] = dict(value=T * sample_rows / dtp, unit="rows/s", cores=T,
+                                sample="%d threads, each the same %d-row partition, %.1f s"
+                                       % (T, sample_rows, dtp))
     os.unlink(path)
-    return dict(value=sample_rows / dt, unit="rows/s", cores=1, kind="port",
-                sample="%d-row instance of the same table/query, oracle (C restatement of "
-                       "FastCSTableScan+VM+GroupBy), %d groups, %.1f s"
-                       % (sample_rows, res.nrows, dt))
+    return out
 
 
 def main():
@@ -115,7 +124,8 @@ def main():
     high_card = args.workload == "config4"
     n_keys = 10_000_000
     nested = args.workload == "config5"
-    rows = args.rows or (125_000_000 if high_card else (20_000_000 if nested else 1_000_000_000))
+    # config 4 = 1.25e8 rows per partition, config 5 = 1e8 records
+    rows = args.rows or (125_000_000 if high_card else (100_000_000 if nested else 1_000_000_000))
     plan_fn = {"config2": B.config2, "config3": B.config3, "config5": config5_plan,
                "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw)}[args.workload]
     gen_kw = dict(u_mod=n_keys) if high_card else {}
@@ -143,6 +153,9 @@ def main():
     elif world > 1:
         max_groups = 4096
         send = torch.zeros(max_groups * rw, dtype=torch.int64, device="cuda")
+        # RCCL: persistent exchange buffers, records exported straight behind the
+        # count word (no staging copy, no allocation inside the timed step)
+        xbuf = D.exchange_buffers(rw, max_groups, world, "cuda") if backend == "nccl" else None
 
     def drain(qq):
         n = 0
@@ -161,8 +174,12 @@ def main():
             return q.stats()["num_groups"] if high_card else drain(q)
         if not high_card:
             # partial aggregates -> dense records -> every rank -> merge kernel
-            n = q.export_groups(send.data_ptr(), max_groups)
-            parts = D.exchange_all_gather(send, n, rw, max_groups)
+            if xbuf is not None:
+                n = q.export_groups(xbuf[0].data_ptr() + 8, max_groups)
+                parts = D.exchange_all_gather(None, n, rw, max_groups, buffers=xbuf)
+            else:
+                n = q.export_groups(send.data_ptr(), max_groups)
+                parts = D.exchange_all_gather(send, n, rw, max_groups)
             foreign, cnt = D.gather_foreign(parts, rank, rw)
             if cnt:
                 q.import_groups(foreign.data_ptr(), cnt)
@@ -270,7 +287,7 @@ def main():
                     sample="%d-record instance, oracle (C restatement of CSTableScan "
                            "NO_AGGREGATION + GroupBy), %d groups, %.1f s" % (n_s, res.nrows, dtc))
             else:
-                sample = args.cpu_sample_rows or (4_000_000 if high_card else 40_000_000)
+                sample = args.cpu_sample_rows or (4_000_000 if high_card else 80_000_000)
                 out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
         if nested:
             # the Dremel flattening (level decode, slot maps, LEB128 decode) runs once

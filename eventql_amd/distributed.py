@@ -31,22 +31,38 @@ def _staged_on_host(records, group):
     return records.device.type == "cuda" and dist.get_backend(group) == "gloo"
 
 
-def exchange_all_gather(records, n, record_words, max_groups, group=None):
+def exchange_buffers(record_words, max_groups, world, device):
+    """persistent (send, recv) buffers for exchange_all_gather: word 0 of a rank's
+    slice = its record count, the records follow -- export straight into
+    send[1:] (data_ptr() + 8) and pass the pair as `buffers`"""
+    width = max_groups * record_words + 1
+    return (torch.zeros(width, dtype=torch.int64, device=device),
+            torch.zeros(world * width, dtype=torch.int64, device=device))
+
+
+def exchange_all_gather(records, n, record_words, max_groups, group=None, buffers=None):
     """records: int64 tensor holding >= n*record_words words (this rank's dense
-    records).  Returns [(tensor_view, count)] for every rank, in rank order."""
-    if _staged_on_host(records, group):
+    records), or None when they were exported into buffers[0][1:] already.
+    Returns [(tensor_view, count)] for every rank, in rank order."""
+    if records is not None and _staged_on_host(records, group):
         parts = exchange_all_gather(records[:n * record_words].cpu(), n, record_words,
                                     max_groups, group)
         return [(t.to(records.device), c) for t, c in parts]
     world = dist.get_world_size(group)
     width = max_groups * record_words + 1
-    send = torch.zeros(width, dtype=torch.int64, device=records.device)
     if n > max_groups:
         raise ValueError("more groups (%d) than the exchange buffer holds (%d)" % (n, max_groups))
-    send[0] = n
-    send[1:1 + n * record_words] = records[:n * record_words]
-    recv = torch.zeros(world * width, dtype=torch.int64, device=records.device)
-    if records.device.type == "cuda":
+    if buffers is not None:
+        send, recv = buffers
+        send[0] = n
+        if records is not None:
+            send[1:1 + n * record_words] = records[:n * record_words]
+    else:
+        send = torch.zeros(width, dtype=torch.int64, device=records.device)
+        send[0] = n
+        send[1:1 + n * record_words] = records[:n * record_words]
+        recv = torch.zeros(world * width, dtype=torch.int64, device=records.device)
+    if send.device.type == "cuda":
         dist.all_gather_into_tensor(recv, send, group=group)
     else:
         parts = [torch.zeros(width, dtype=torch.int64) for _ in range(world)]

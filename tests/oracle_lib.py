@@ -310,6 +310,39 @@ def oracle_run(path_or_image, plan, order=None):
         L.orc_table_close(t)
 
 
+def oracle_time_parallel(path, plans):
+    """wall-clock seconds of len(plans) concurrent orc_query_run calls over the same
+    file, one thread each (ctypes releases the GIL; tables are opened and results
+    freed outside the timed region) -- bench.py's all-cores CPU figure"""
+    import threading
+    import time
+    L = oracle()
+    tables = [L.orc_table_open(path.encode()) for _ in plans]
+    if not all(tables):
+        raise IOError(L.orc_last_error().decode())
+    results = [None] * len(plans)
+
+    def work(i):
+        results[i] = L.orc_query_run(tables[i], C.byref(plans[i].desc))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(plans))]
+    t0 = time.time()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.time() - t0
+    ok = all(results)
+    for r in results:
+        if r:
+            L.orc_result_free(r)
+    for t in tables:
+        L.orc_table_close(t)
+    if not ok:
+        raise RuntimeError("oracle run failed")
+    return dt
+
+
 def _collect(L, r):
     nc = L.orc_result_num_columns(r)
     nrows = L.orc_result_num_rows(r)

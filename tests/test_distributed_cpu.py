@@ -117,6 +117,13 @@ def _worker(rank, world, port, n_parts, rows, key, mode, q):
         t = torch.from_numpy(dense.reshape(-1).copy())
         if mode == "all_gather":
             parts = D.exchange_all_gather(t, len(local), RW, max_groups=8192)
+            # same exchange through persistent buffers with the records laid out
+            # behind the count word (the RCCL path of bench.py)
+            xbuf = D.exchange_buffers(RW, 8192, world, "cpu")
+            xbuf[0][1:1 + t.numel()] = t
+            parts2 = D.exchange_all_gather(None, len(local), RW, 8192, buffers=xbuf)
+            assert [c for _, c in parts2] == [c for _, c in parts]
+            assert all(torch.equal(a, b) for (a, _), (b, _) in zip(parts, parts2))
             # own records + everybody else's as one contiguous block (what bench.py
             # hands to evql_query_import_groups)
             foreign, cnt = D.gather_foreign(parts, rank, RW)
