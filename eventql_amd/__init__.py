@@ -196,7 +196,8 @@ class Writer:
     def image(self):
         n = C.c_uint64()
         p = lib().evql_writer_image(self.h, C.byref(n))
-        return C.string_at(p, n.value)
+        # (ctypes.string_at takes a C int: images beyond 2 GiB need the array form)
+        return bytes((C.c_ubyte * n.value).from_address(p))
 
     def write_file(self, path):
         _check(lib().evql_writer_write_file(self.h, path.encode()))

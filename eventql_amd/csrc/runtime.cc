@@ -108,6 +108,9 @@ Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out, boo
       HIP_TRY(hipModuleGetFunction(&out->fn_count, out->mod, "evql_part_count"));
       HIP_TRY(hipModuleGetFunction(&out->fn_scatter, out->mod, "evql_part_scatter"));
       HIP_TRY(hipModuleGetFunction(&out->fn_aggregate, out->mod, "evql_part_aggregate"));
+      if (source.find("evql_part_refine") != std::string::npos) {
+        HIP_TRY(hipModuleGetFunction(&out->fn_refine, out->mod, "evql_part_refine"));
+      }
     }
     if (ctx) ctx->modules[key] = *out;
   }
@@ -242,6 +245,8 @@ evql_query::~evql_query() {
   if (d_part_counts) hipFree(d_part_counts);
   if (d_bucket_start) hipFree(d_bucket_start);
   if (d_tuples) hipFree(d_tuples);
+  if (d_tuples_tmp) hipFree(d_tuples_tmp);
+  if (d_part_cursors) hipFree(d_part_cursors);
   for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
@@ -844,7 +849,11 @@ Status query_launch(evql_query* q) {
   const KernelPlan& kp = q->kp;
   hipStream_t s = ctx->stream;
   if (!q->d_gtab) {
-    uint64_t want = kp.key_mode == KEY_NONE ? 8 : std::max<uint64_t>(q->groups_hint * 4, 1 << 16);
+    // load factor <= 1/4 for small tables; very large ones (>= 1M groups) are kept
+    // at <= 1/2: initialising and scanning the table is then a visible part of a
+    // step (2.7 GB of slots for 1e7 groups at 1/4)
+    const uint64_t slack = q->groups_hint >= (1ull << 20) ? 2 : 4;
+    uint64_t want = kp.key_mode == KEY_NONE ? 8 : std::max<uint64_t>(q->groups_hint * slack, 1 << 16);
     uint64_t cap = 8;
     while (cap < want) cap <<= 1;
     Status st = alloc_gtab(q, cap);
@@ -920,14 +929,20 @@ Status query_launch(evql_query* q) {
     ap.a = a;
     ap.p.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
     ap.p.nwg = nwg;
+    const bool two_level = q->module.fn_refine != nullptr;
+    const uint64_t ncursors = 256 + npart;  // [coarse] + [fine]
     if (!q->d_part_counts) {
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_part_counts),
                         npart * uint64_t(q->grid) * sizeof(uint32_t)));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_bucket_start), (npart + 2) * 8));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_part_cursors), ncursors * 4));
     }
     ap.p.counts = q->d_part_counts;
     ap.p.bucket_start = q->d_bucket_start;
     ap.p.tuples = q->d_tuples;
+    ap.p.tuples_tmp = q->d_tuples_tmp;
+    ap.p.cursors = q->d_part_cursors;
+    HIP_TRY(hipMemsetAsync(q->d_part_cursors, 0, ncursors * 4, s));
     size_t psz = sizeof(HostArgsWithPart);
     void* pconfig[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ap, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz,
                        HIP_LAUNCH_PARAM_END};
@@ -938,22 +953,36 @@ Status query_launch(evql_query* q) {
     HIP_TRY(launch_part_scan(q->d_part_counts, npart, nwg, q->d_bucket_start, s));
     uint64_t* d_total = q->d_bucket_start + npart + 1;
     HIP_TRY(launch_exclusive_scan(q->d_bucket_start, npart + 1, d_total, s));
-    uint64_t ntuples = 0;
-    HIP_TRY(hipMemcpyAsync(&ntuples, d_total, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t tw = uint64_t(kp.first_row_word() + (kp.need_first_row ? 1 : 0)) +
+                        uint64_t(q->n_update_words);
+    const uint64_t span = a.row_end - a.row_begin;
+    uint64_t ntuples = span;  // upper bound: every row passes
+    if (q->tuples_cap < span && span * tw * 8 > (16ull << 30)) {
+      // large scans with a selective predicate: size the buffers by the count pass
+      HIP_TRY(hipMemcpyAsync(&ntuples, d_total, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
     if (ntuples > q->tuples_cap) {
       if (q->d_tuples) hipFree(q->d_tuples);
-      q->d_tuples = nullptr;
+      if (q->d_tuples_tmp) hipFree(q->d_tuples_tmp);
+      q->d_tuples = q->d_tuples_tmp = nullptr;
       const uint64_t cap = ntuples + ntuples / 16 + 1024;
-      const uint64_t tw = uint64_t(kp.first_row_word() + (kp.need_first_row ? 1 : 0)) +
-                          uint64_t(q->n_update_words);
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_tuples), cap * tw * 8));
+      if (two_level) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_tuples_tmp), cap * tw * 8));
       q->tuples_cap = cap;
     }
     ap.p.tuples = q->d_tuples;
+    ap.p.tuples_tmp = q->d_tuples_tmp;
     HIP_TRY(hipModuleLaunchKernel(q->module.fn_scatter, unsigned(nwg), 1, 1, kp.block, 1, 1, 0, s,
                                   nullptr, pconfig));
-    const unsigned agrid = unsigned(std::min<uint64_t>(npart, uint64_t(q->grid)));
+    // two workgroups per CU where the resources allow it: both passes wait on
+    // dependent loads (tuple -> slot) and hide each other's latency
+    const uint64_t wide = std::max<uint64_t>(uint64_t(q->grid), uint64_t(ctx->num_cus) * 2);
+    if (two_level) {
+      HIP_TRY(hipModuleLaunchKernel(q->module.fn_refine, unsigned(wide), 1, 1, kp.block, 1, 1, 0, s,
+                                    nullptr, pconfig));
+    }
+    const unsigned agrid = unsigned(std::min<uint64_t>(npart, wide));
     HIP_TRY(hipModuleLaunchKernel(q->module.fn_aggregate, agrid, 1, 1, kp.block, 1, 1, 0, s, nullptr,
                                   pconfig));
     HIP_TRY(hipEventRecord(q->ev1, s));

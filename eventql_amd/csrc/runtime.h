@@ -54,6 +54,7 @@ struct Module {
   hipFunction_t fn = nullptr;
   // partitioned high-cardinality path (present only when the plan asks for it)
   hipFunction_t fn_count = nullptr, fn_scatter = nullptr, fn_aggregate = nullptr;
+  hipFunction_t fn_refine = nullptr;  // second scatter level (part_bits > 8)
   size_t code_size = 0;
 };
 
@@ -64,6 +65,8 @@ struct HostPartArgs {
   const uint64_t* bucket_start;
   uint64_t* tuples;
   uint64_t nwg;
+  uint64_t* tuples_tmp;
+  uint32_t* cursors;
 };
 struct HostArgsWithPart {
   HostArgs a;
@@ -126,6 +129,8 @@ struct evql_query {
   uint32_t* d_part_counts = nullptr;
   uint64_t* d_bucket_start = nullptr;
   uint64_t* d_tuples = nullptr;
+  uint64_t* d_tuples_tmp = nullptr;  // coarse-bucket order (two-level scatter)
+  uint32_t* d_part_cursors = nullptr;
   uint64_t tuples_cap = 0;  // in tuples
   int n_update_words = 0;   // update words per row (tuple payload)
   // nested (Dremel) scans: flattened per-row SoA columns, one per scan column

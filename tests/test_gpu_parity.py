@@ -98,13 +98,22 @@ def test_partitioned_high_cardinality_path(mixed, monkeypatch):
         dict(select=[col("b"), count(1), sum_(col("v"))], group_by=[col("b")], row_end=123_457),
     ):
         kc = kw.pop("key_cols", 1)
-        q_src = None
-        got, exp, st = check(t, img, key_cols=kc, groups_hint=300_000, **kw)
+        # 256 buckets: one scatter level; 1024 / 4096 buckets: coarse + refine
+        for hint in (100_000, 300_000, 3_000_000):
+            got, exp, st = check(t, img, key_cols=kc, groups_hint=hint, **kw)
     # the kernels really are the partitioned ones
     plan = Plan(T.MIXED_SCHEMA, select=[col("w"), count(1)], group_by=[col("w")],
                 groups_hint=300_000)
     q = t.query(plan)
     assert "evql_part_scatter" in q.kernel_source()
+    q.close()
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[col("w"), count(1)], group_by=[col("w")],
+                     groups_hint=3_000_000))
+    assert "evql_part_refine" in q.kernel_source()
+    q.close()
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[col("w"), count(1)], group_by=[col("w")],
+                     groups_hint=100_000))
+    assert "evql_part_refine" not in q.kernel_source()
     q.close()
     monkeypatch.setenv("EVQL_FORCE_PARTITIONED", "0")
     q = t.query(plan)
