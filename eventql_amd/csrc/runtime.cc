@@ -238,6 +238,7 @@ evql_query::~evql_query() {
   if (d_gtab) hipFree(d_gtab);
   if (d_status) hipFree(d_status);
   if (d_counters) hipFree(d_counters);
+  if (d_small_rec) hipFree(d_small_rec);
   for (auto* p : d_pairset) {
     if (p) hipFree(p);
   }
@@ -986,8 +987,11 @@ Status query_launch(evql_query* q) {
     HIP_TRY(hipModuleLaunchKernel(q->module.fn_aggregate, agrid, 1, 1, kp.block, 1, 1, 0, s, nullptr,
                                   pconfig));
     HIP_TRY(hipEventRecord(q->ev1, s));
+    // group count into counter word 4 (read back by finish together with the rest)
+    HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, uint32_t(kp.words_per_slot()),
+                                 nullptr, 0, q->d_counters + 4, s));
     q->launched = true;
-    q->stats.n_kernel_launches = 6;
+    q->stats.n_kernel_launches = 7;
     q->stats.rows_scanned = a.row_end - a.row_begin;
     return Status();
   }
@@ -1001,8 +1005,11 @@ Status query_launch(evql_query* q) {
     HIP_TRY(hipModuleLaunchKernel(q->module.fn, grid, 1, 1, kp.block, 1, 1, 0, s, nullptr, config));
   }
   HIP_TRY(hipEventRecord(q->ev1, s));
+  // group count into counter word 4 (read back by finish together with the rest)
+  HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, uint32_t(kp.words_per_slot()),
+                               nullptr, 0, q->d_counters + 4, s));
   q->launched = true;
-  q->stats.n_kernel_launches = 2;
+  q->stats.n_kernel_launches = 3;
   q->stats.rows_scanned = a.row_end - a.row_begin;
   return Status();
 }
@@ -1047,20 +1054,10 @@ Status query_finish(evql_query* q) {
     q->launched = false;
     // the groups stay in HBM; they are compacted and copied to the host only
     // when the first nextBatch asks for them (a partial aggregate that is merged
-    // on the device never leaves it).  Only the group count is read back.
-    {
-      // (counter word 4 of the per-query counter block: no allocation per step)
-      uint64_t* d_cnt = q->d_counters + 4;
-      HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8,
-                                   uint32_t(q->kp.words_per_slot()), nullptr, 0, d_cnt,
-                                   ctx->stream));
-      uint64_t n = 0;
-      HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      q->ngroups = n;
-      q->stats.num_groups = n;
-    }
+    // on the device never leaves it).  Only the group count is read back: the
+    // count pass was enqueued behind the kernels by launch (counter word 4).
+    q->ngroups = counters[4];
+    q->stats.num_groups = counters[4];
     q->executed = true;
     q->fetched = false;
     q->emit_pos = 0;
@@ -1141,8 +1138,18 @@ static Status fetch_results(evql_query* q) {
   uint64_t n = q->stats.num_groups;
   if (n > maxrec) n = maxrec;
   const uint64_t total_groups = n;
+  // small results (the usual case) reuse a per-query 1 MiB buffer: no allocation
+  // inside a step
+  const size_t kSmallRec = 1 << 20;
+  bool rec_owned = true;
   if (n) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec), n * (nwords + 1) * 8));
+    if (n * (nwords + 1) * 8 <= kSmallRec) {
+      if (!q->d_small_rec) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_small_rec), kSmallRec));
+      d_rec = q->d_small_rec;
+      rec_owned = false;
+    } else {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec), n * (nwords + 1) * 8));
+    }
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
     HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec, n, d_cnt, s));
   }
@@ -1188,8 +1195,9 @@ static Status fetch_results(evql_query* q) {
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec2), std::max<uint64_t>(m, 1) * (nwords + 1) * 8));
       HIP_TRY(launch_gather_records(d_rec, nwords + 1, d_idx, m, d_rec2, s));
       HIP_TRY(hipStreamSynchronize(s));
-      hipFree(d_rec);
+      if (rec_owned) hipFree(d_rec);
       d_rec = d_rec2;
+      rec_owned = true;
       hipFree(d_keys);
       hipFree(d_hist);
       hipFree(d_idx);
@@ -1265,7 +1273,7 @@ static Status fetch_results(evql_query* q) {
     hipFree(d_vals);
     hipFree(d_tags);
   }
-  if (d_rec) hipFree(d_rec);
+  if (d_rec && rec_owned) hipFree(d_rec);
   q->stats.num_groups = total_groups;
   q->emit_pos = 0;
   q->executed = true;

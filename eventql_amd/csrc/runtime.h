@@ -145,6 +145,7 @@ struct evql_query {
   uint64_t gcap = 0;
   uint32_t* d_status = nullptr;
   uint64_t* d_counters = nullptr;
+  uint64_t* d_small_rec = nullptr;  // 1 MiB: dense records of small results
   // count_distinct pair sets (3 word planes of pairset_cap slots each)
   uint64_t* d_pairset[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t pairset_cap = 0;
