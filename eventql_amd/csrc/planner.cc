@@ -245,6 +245,18 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     if (!strings_lowerable(q->where.call)) return unsup("string expression is not lowerable");
     q->has_where = true;
     kp.where = q->where.call;
+    if (nested && kp.cols.empty()) {
+      // CSTableScan::fetchNextWithoutColumns (CSTableScan.cc:551-564) skips the
+      // record when the predicate is TRUE (`if (popBool(..)) continue;`): a scan
+      // that reads no column emits its rows exactly when WHERE is false
+      auto neg = std::make_shared<Expr>();
+      neg->kind = Expr::CALL;
+      neg->type = EVQL_T_BOOL;
+      neg->family = EVQL_FAM_NEG;
+      neg->type_slot = EVQL_TS_BOOL;
+      neg->args.push_back(kp.where);
+      kp.where = neg;
+    }
     mark_string_bytes(kp.where, &kp.cols);
   }
   q->scan_select.resize(plan->n_scan_select);

@@ -145,7 +145,8 @@ typedef enum {
   EVQL_AGG_SUM_UINT64 = 2,  /* sum#uint64/uint64;     wraps mod 2^64        */
   EVQL_AGG_SUM_INT64 = 3,   /* sum#int64/int64;                             */
   EVQL_AGG_SUM_FLOAT64 = 4, /* sum#float64/float64;   build-supplied        */
-  EVQL_AGG_MIN_UINT64 = 5,  /* min/max/mean skip STAG_NULL inputs; empty => NULL */
+  EVQL_AGG_MIN_UINT64 = 5,  /* min/max/mean skip STAG_NULL inputs (float min/max
+                             * also NaN); empty => NULL */
   EVQL_AGG_MAX_UINT64 = 6,
   EVQL_AGG_MIN_INT64 = 7,
   EVQL_AGG_MAX_INT64 = 8,

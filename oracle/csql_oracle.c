@@ -20,7 +20,9 @@
  *     tag (exactly what sum_uint64 does, aggregate.cc:184-219); empty => 0.0
  *   - min/max/mean skip STAG_NULL inputs (legacy bodies aggregate.cc:225-441
  *     skip NIL); over zero non-NULL inputs the result is NULL (value 0, tag 1);
- *     mean accumulates (double) value in row order and divides on get
+ *     mean accumulates (double) value in row order and divides on get;
+ *     float min/max also skip NaN inputs (the legacy `first value initialises`
+ *     rule would make the result depend on where in the scan a NaN appears)
  * Deliberate non-reproductions of reference *bugs*:
  *   - the evaluateVector X_INPUT shortcut (vm.cc:189-199) is applied only to
  *     programs that are exactly a bare column reference, where it is
@@ -492,6 +494,9 @@ static int agg_accumulate(uint32_t fn, agg_t* a, vmstack_t* s) {
     case EVQL_AGG_MAX_FLOAT64: {
       double v = pop_f64(s, &tag), cur;
       if (tag & EVQL_STAG_NULL) return 0;
+      /* NaN inputs are skipped like NULLs: with `first value initialises` a NaN
+       * would stick or vanish depending on the row order */
+      if (v != v) return 0;
       memcpy(&cur, &a->w0, 8);
       if (a->w1 == 0 || (fn == EVQL_AGG_MIN_FLOAT64 ? v < cur : v > cur)) {
         memcpy(&a->w0, &v, 8);

@@ -162,6 +162,80 @@ def test_random_plan(mixed, seed):
     run_case(t, img, T.MIXED_SCHEMA, kw)
 
 
+# ---- nested (Dremel) scans ------------------------------------------------------------------
+def _nested_gens():
+    import nested_tables as N
+    items = dict(uint_cols=["id", "items.position", "items.price"], float_cols=["score"],
+                 bool_cols=[], key_cols=["items.position", "id"], first_cols=["items.price", "id"],
+                 lits=[0, 1, 3, 7, 1000, 50000, 1 << 33])
+    fixture = dict(uint_cols=["time", "event.search_query.time",
+                              "event.search_query.num_result_items",
+                              "event.search_query.result_items.position"],
+                   float_cols=[], bool_cols=["event.search_query.result_items.clicked"],
+                   key_cols=["event.search_query.result_items.position",
+                             "event.search_query.num_result_items",
+                             "event.search_query.result_items.clicked"],
+                   first_cols=["time", "event.search_query.num_result_items"],
+                   lits=[0, 1, 2, 6, 10, 1438055327])
+    return N, items, fixture
+
+
+@pytest.fixture(scope="module")
+def nested(ctx):
+    N, _, _ = _nested_gens()
+    img_items, _ = N.items_table(50_000)
+    img_fix = N.testtbl_v2()
+    ti, tf = ctx.open_image(img_items), ctx.open_image(img_fix)
+    yield (ti, img_items), (tf, img_fix)
+    ti.close()
+    tf.close()
+
+
+class NestedGen(Gen):
+    """float productions without a float column use literals; WHERE draws from the
+    leaf-level columns only (a WHERE over columns of different repetition depth
+    is answered with ENOTSUP, see planner.cc)"""
+    leaf_uint, leaf_bool = (), ()
+
+    def flt(self, depth=0):
+        if not self.float_cols:
+            return Lit(self.r.choice([0.0, 1.5, -2.25, 100.0]))
+        return Gen.flt(self, depth)
+
+    def plan_kwargs(self, row_ends):
+        # a WHERE is lowered only when every scan column has the same repetition
+        # depth (the reference's reset quirk): half of the plans use leaf columns
+        # only and keep their WHERE, the others use all columns without one
+        if self.r.random() < 0.5:
+            self.uint_cols = list(self.leaf_uint)
+            self.float_cols, self.bool_cols = [], list(self.leaf_bool)
+            self.key_cols = list(self.leaf_uint) + list(self.leaf_bool)
+            self.first_cols = list(self.leaf_uint)
+            return Gen.plan_kwargs(self, row_ends)
+        kw = Gen.plan_kwargs(self, row_ends)
+        kw.pop("where", None)
+        return kw
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_nested_plan(nested, seed):
+    N, items, fixture = _nested_gens()
+    (ti, img_items), (tf, img_fix) = nested
+    which = seed % 2
+    t, img, schema, cols = ((ti, img_items, N.ITEMS_SCHEMA, items) if which == 0 else
+                            (tf, img_fix, N.NESTED_SCHEMA, fixture))
+    g = NestedGen(2000 + seed, **cols)
+    if which == 0:
+        g.leaf_uint, g.leaf_bool = ["items.position", "items.price"], []
+    else:
+        g.leaf_uint = ["event.search_query.result_items.position"]
+        g.leaf_bool = ["event.search_query.result_items.clicked"]
+    kw = g.plan_kwargs([1])
+    kw.pop("row_end", None)  # row ranges do not apply to nested scans
+    kw["scan_mode"] = K.SCAN_NESTED
+    run_case(t, img, schema, kw)
+
+
 # ---- full-range columns -------------------------------------------------------------------
 RANGES_SCHEMA = dict(x17=K.T_UINT64, x24=K.T_UINT64, x31=K.T_UINT64, x32=K.T_UINT64,
                      p32=K.T_UINT64, q64=K.T_UINT64, l64=K.T_UINT64, g=K.T_UINT64,

@@ -515,6 +515,9 @@ def test_nested_scan_known_answers(ctx):
     clicked = col("event.search_query.result_items.clicked")
     cases = [
         (dict(select=[count(1)]), [(213,)]),                             # no columns: per record
+        # fetchNextWithoutColumns skips a record when WHERE is TRUE (CSTableScan.cc:551-564)
+        (dict(select=[count(1)], where=lit(1) > lit(2)), [(213,)]),
+        (dict(select=[count(1)], where=lit(2) > lit(1)), []),
         (dict(select=[count(sq_time)]), [(773,)]),                       # 704 defined + 69 empty
         (dict(select=[count(1)], where=sq_time > 0), [(704,)]),
         (dict(select=[sum_(nitems)]), [(24793,)]),
