@@ -14,7 +14,8 @@ from . import capi as K
 from .plan import Plan, unpack_svector  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevql_mi355x.so")
+# EVQL_LIB: an instrumented build of the same library (host-side sanitizer runs)
+LIB_PATH = os.environ.get("EVQL_LIB") or os.path.join(_HERE, "libevql_mi355x.so")
 KERNEL_CACHE_DIR = os.path.join(_HERE, "_kcache")
 
 _u64p = C.POINTER(C.c_uint64)

@@ -18,7 +18,9 @@ from eventql_amd.plan import unpack_svector
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+# EVQL_ORACLE_SO: an instrumented build (oracle/Makefile `asan`), run with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so)
+ORACLE_SO = os.environ.get("EVQL_ORACLE_SO") or os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libcstable_ref.so")
 
 _u64p = C.POINTER(C.c_uint64)
