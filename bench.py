@@ -36,6 +36,8 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 QUERIES = {
     "config2": ("k, sum(v), count(1) GROUP BY k", "kv", 2),
     "config3": ("k, sum(v), count(1), sum(b) WHERE a>30000 AND b<30000 GROUP BY k", "kabv", 4),
+    # config 3 over the reference's default integer encoding (k, a, b UINT64_LEB128)
+    "config3l": ("k, sum(v), count(1), sum(b) WHERE a>30000 AND b<30000 GROUP BY k", "kabv", 4),
     "config4": ("u, sum(a), count(1), sum(v) GROUP BY u  (u uniform in [0,1e7))", "uav", 3),
     # nested: REPEATED RECORD items{position, price}, Dremel flattening (CSTableScan)
     "config5": ("items.position, count(1), sum(items.price) GROUP BY items.position "
@@ -125,8 +127,10 @@ def main():
     n_keys = 10_000_000
     nested = args.workload == "config5"
     # config 4 = 1.25e8 rows per partition, config 5 = 1e8 records
-    rows = args.rows or (125_000_000 if high_card else (100_000_000 if nested else 1_000_000_000))
-    plan_fn = {"config2": B.config2, "config3": B.config3, "config5": config5_plan,
+    rows = args.rows or (125_000_000 if high_card else
+                         (100_000_000 if nested or args.workload == "config3l" else 1_000_000_000))
+    plan_fn = {"config2": B.config2, "config3": B.config3, "config3l": B.config3,
+               "config5": config5_plan,
                "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw)}[args.workload]
     gen_kw = dict(u_mod=n_keys) if high_card else {}
     if args.k_bits:
@@ -136,7 +140,29 @@ def main():
     # every rank owns one partition; different seeds => different partitions
     seed = synth.SEED if rank == 0 else (synth.SEED + 0x9E3779B97F4A7C15 * rank) & synth.MASK
     nested_image = None
-    if nested:
+    leb = args.workload == "config3l"
+    materialize_ms = None
+    if leb:
+        # config 3's table with the reference's DEFAULT integer encoding
+        # (UINT64_LEB128, TableSchema.cc:290-316), written by the host writer; the
+        # first operator decodes the three columns to SoA on the device, once
+        from eventql_amd import capi as K
+        c = synth.table_columns(rows, seed=seed)
+        w = E.Writer([dict(name=n, logical_type=K.COL_UNSIGNED_INT,
+                           storage_type=K.ENC_UINT64_LEB128) for n in "kab"] +
+                     [dict(name="v", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754)])
+        for n in "kabv":
+            w.put(n, c[n])
+        w.commit(rows)
+        table = ctx.open_image(w.image())
+        w.close()
+        del c
+        ctx.synchronize()
+        t0m = time.perf_counter()
+        table.query(plan_fn()).close()
+        ctx.synchronize()
+        materialize_ms = (time.perf_counter() - t0m) * 1e3
+    elif nested:
         # `rows` = records; written by the host writer (levels + LEB128 / bit-packed
         # data), then resident in HBM like any other table
         nested_image, nested_stats = synth.items_table_image(rows, seed=3 + rank)
@@ -255,7 +281,8 @@ def main():
                 "query": query_text,
                 "rows_per_gpu": rows,
                 "columns": ncols,
-                "encodings": ("UINT64_PLAIN/FLOAT_IEEE754" if not args.k_bits else
+                "encodings": ("k, a, b UINT64_LEB128 (decoded to SoA once per table), v FLOAT_IEEE754"
+                              if leb else "UINT64_PLAIN/FLOAT_IEEE754" if not args.k_bits else
                               "k UINT32_BITPACKED(%d bit), others UINT64_PLAIN/FLOAT_IEEE754"
                               % args.k_bits),
                 "groups": int(ngroups_out),
@@ -274,7 +301,7 @@ def main():
                 "kernel_ms": avg_kernel_ms,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not leb:
             if nested:
                 import oracle_lib as O
                 n_s = min(rows, args.cpu_sample_rows or 2_000_000)
@@ -289,6 +316,8 @@ def main():
             else:
                 sample = args.cpu_sample_rows or (4_000_000 if high_card else 80_000_000)
                 out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
+        if leb:
+            out["config"]["materialize_ms_first_operator"] = materialize_ms
         if nested:
             # the Dremel flattening (level decode, slot maps, LEB128 decode) runs once
             # when the operator is created, not per step: report it separately
