@@ -170,7 +170,10 @@ def main():
     else:
         table = ctx.generate(rows, columns, seed=seed, **gen_kw)
     ctx.synchronize()
+    t0q = time.perf_counter()
     q = table.query(plan_fn())
+    ctx.synchronize()
+    first_operator_ms = (time.perf_counter() - t0q) * 1e3
     rw = q.record_words()
     qm = None
     if world > 1 and high_card:
@@ -319,13 +322,16 @@ def main():
         if leb:
             out["config"]["materialize_ms_first_operator"] = materialize_ms
         if nested:
-            # the Dremel flattening (level decode, slot maps, LEB128 decode) runs once
-            # when the operator is created, not per step: report it separately
+            # the Dremel flattening (level decode, slot maps, LEB128 decode) runs when
+            # the first operator over these columns is created (together with the
+            # hiprtc compile of the plan) and is cached on the table; later operators
+            # reuse the flattened columns
             ctx.synchronize()
             t0p = time.perf_counter()
             q2 = table.query(plan_fn())
             ctx.synchronize()
-            out["config"]["flatten_ms_at_operator_creation"] = (time.perf_counter() - t0p) * 1e3
+            out["config"]["first_operator_ms_flatten_and_jit"] = first_operator_ms
+            out["config"]["next_operator_ms"] = (time.perf_counter() - t0p) * 1e3
             q2.close()
             out["config"]["records_per_gpu"] = rows
             out["config"]["flattened_rows_per_gpu"] = int(stats["rows_scanned"])

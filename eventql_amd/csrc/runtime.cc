@@ -232,6 +232,9 @@ evql_table::~evql_table() {
     if (kv.second.d_tags) hipFree(kv.second.d_tags);
     if (kv.second.d_strpos) hipFree(kv.second.d_strpos);
   }
+  for (auto& kv : nested_cache) {
+    if (kv.second.d_values) hipFree(kv.second.d_values);
+  }
 }
 
 evql_query::~evql_query() {
@@ -674,6 +677,20 @@ static Status materialize_nested(evql_query* q) {
     }
   }
   const ColumnLayout& lc = t->layout.columns[kp.cols[leaf].layout_index];
+  const int leaf_li = kp.cols[leaf].layout_index;
+  {
+    // every column already flattened for this leaf by an earlier operator?
+    bool all = true;
+    for (const auto& c : kp.cols) all = all && t->nested_cache.count({c.layout_index, leaf_li});
+    if (all) {
+      for (size_t i = 0; i < kp.cols.size(); ++i) {
+        const auto& e = t->nested_cache[{kp.cols[i].layout_index, leaf_li}];
+        q->nested_flat[i] = e.d_values;
+        q->nested_rows = e.nflat;
+      }
+      return Status();
+    }
+  }
   uint64_t nflat = nrec;
   uint8_t* d_leaf_levels = nullptr;
   std::vector<uint32_t> thr_levels;       // distinct parent rlevel_max values
@@ -741,6 +758,13 @@ static Status materialize_nested(evql_query* q) {
     }
     if (shared) continue;
     const int li = kp.cols[i].layout_index;
+    {
+      auto hit = t->nested_cache.find({li, leaf_li});
+      if (hit != t->nested_cache.end()) {
+        q->nested_flat[i] = hit->second.d_values;
+        continue;
+      }
+    }
     const ColumnLayout& c = t->layout.columns[li];
     uint64_t* d_vals = nullptr;
     uint64_t cap = 0;
@@ -753,7 +777,7 @@ static Status materialize_nested(evql_query* q) {
         return Status::error(EVQL_ENOTSUP, "nested columns from different repeated groups");
       }
       q->nested_flat[i] = d_vals;
-      q->nested_owned.push_back(d_vals);
+      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_vals, nflat};
     } else {
       size_t k = 0;
       while (thr_levels[k] != c.rlevel_max) ++k;
@@ -765,7 +789,7 @@ static Status materialize_nested(evql_query* q) {
       HIP_TRY(hipStreamSynchronize(s));
       hipFree(d_vals);
       q->nested_flat[i] = d_flat;
-      q->nested_owned.push_back(d_flat);
+      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_flat, nflat};
     }
   }
   if (d_leaf_levels) hipFree(d_leaf_levels);

@@ -106,6 +106,14 @@ struct evql_table {
   std::vector<std::vector<uint64_t*>> d_pages;
   std::vector<uint64_t> payload_bytes;
   std::map<std::string, MaterializedColumn> materialized;
+  // nested scans: column flattened to one value per output row of the scans whose
+  // deepest repeated column is `leaf` -- key (column, leaf) layout indices.  Like
+  // `materialized`, decoded once per table and shared by every operator.
+  struct NestedFlat {
+    uint64_t* d_values = nullptr;
+    uint64_t nflat = 0;
+  };
+  std::map<std::pair<int, int>, NestedFlat> nested_cache;
   ~evql_table();
 };
 
