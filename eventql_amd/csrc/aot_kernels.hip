@@ -225,14 +225,23 @@ __global__ void __launch_bounds__(kBlock) k_expand_nullable(const u8* image, RtC
 #pragma unroll
   for (int j = 0; j < 8; ++j) cnt += ((packed >> (8 * j)) & 1) ? 0 : (r0 + j < nrows ? 1 : 0);
   u32 total;
-  u64 idx = tile_offsets[tile] + block_excl_scan(cnt, &total);
+  u32 li = block_excl_scan(cnt, &total);
+  // row -> index of its value inside the tile (0xffff = undefined), staged in LDS so
+  // that the gather and the stores below run with consecutive lanes on consecutive
+  // rows (8 rows per lane made both strided: 0.57 ms per 4.3e7 slots)
+  __shared__ unsigned short vidx[kDecodeTile];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const u64 r = r0 + j;
-    const bool defined = !((packed >> (8 * j)) & 1) && r < nrows;
-    u64 v = 0;
-    if (defined) v = rt_column_value(image, src, idx++);
-    values[r] = v;  // padded to a tile multiple
+    const bool defined = !((packed >> (8 * j)) & 1) && r0 + j < nrows;
+    vidx[threadIdx.x * 8 + j] = defined ? (unsigned short) li++ : (unsigned short) 0xffff;
+  }
+  __syncthreads();
+  const u64 base = tile_offsets[tile];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u32 row = (u32) k * kBlock + threadIdx.x;
+    const u32 x = vidx[row];
+    values[tile * kDecodeTile + row] = x == 0xffffu ? 0 : rt_column_value(image, src, base + x);
   }
 }
 
