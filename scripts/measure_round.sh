@@ -12,6 +12,7 @@ python bench.py --steps 20 --warmup 3 > "$OUT/bench_config3.json" 2> "$OUT/bench
 python bench.py --steps 20 --warmup 3 --workload config2 > "$OUT/bench_config2.json" 2> "$OUT/bench_config2.err"
 python bench.py --steps 20 --warmup 3 --workload config2 --k-bits 10 --no-cpu-baseline \
   > "$OUT/bench_config2_bitpacked.json" 2> "$OUT/bench_config2_bitpacked.err"
+python bench.py --steps 20 --warmup 3 --workload config3l > "$OUT/bench_config3_leb128.json" 2> "$OUT/bench_config3_leb128.err"
 echo "[measure] config4 / config5"; date
 python bench.py --steps 10 --warmup 2 --workload config4 > "$OUT/bench_config4.json" 2> "$OUT/bench_config4.err"
 python bench.py --steps 20 --warmup 3 --workload config5 > "$OUT/bench_config5.json" 2> "$OUT/bench_config5.err"
