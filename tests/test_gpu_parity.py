@@ -392,6 +392,45 @@ def test_every_bit_width_in_the_fused_kernel(ctx, bits):
     t.close()
 
 
+def test_operators_release_their_device_memory(ctx):
+    """create / run / destroy many operators of every kind (LDS path, partitioned
+    path, pair sets, ORDER BY, nested, string predicates) on one table: HBM in use
+    returns to where it was (tables keep their decoded-column caches, so the
+    baseline is taken after one warm-up round)"""
+    import torch
+    from eventql_amd.plan import count_distinct, Order
+    img, _ = T.mixed_table(300_000)
+    t = ctx.open_image(img)
+    k, a, w, s = col("k"), col("a"), col("w"), col("s")
+    plans = [
+        (dict(select=[k, count(1), sum_(a)], group_by=[k], where=W), None),
+        (dict(select=[w, count(1), sum_(a)], group_by=[w], groups_hint=3_000_000), None),
+        (dict(select=[k, count_distinct(a)], group_by=[k]), None),
+        (dict(select=[k, count(1), sum_(a)], group_by=[k]), [(2, True)]),
+        (dict(select=[s, count(1)], group_by=[s], where=s.neq("g7")), None),
+        (dict(select=[count(1), sum_(col("v"))]), None),
+    ]
+
+    def one_round():
+        for kw, order in plans:
+            plan = Plan(T.MIXED_SCHEMA, **kw)
+            q = t.query(plan)
+            if order:
+                q.set_order(Order(plan, order, limit=5))
+            q.run()
+            q.close()
+
+    one_round()
+    ctx.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        one_round()
+    ctx.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)
+    t.close()
+
+
 def test_count_distinct(mixed, monkeypatch):
     """count_distinct#uint64/uint64; (aggregate.cc:77-137): exact, through the HBM
     pair set, under every key mode, next to other aggregates"""
