@@ -91,7 +91,9 @@ typedef u32 evql_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ void evql_plain64_x2(const u8* image, const u64* pages,
                                                 u64 r, u64& v0, u64& v1) {
   const u8* p = image + pages[r >> 16] + ((r & 0xffffull) << 3);
-  evql_u32x4 q = *reinterpret_cast<const evql_u32x4*>(p);
+  // column pages are streamed once: non-temporal loads (measured on MI355X, 32 GB
+  // pure-read stream: 6.0-6.1 TB/s with plain loads, 6.5-6.8 TB/s non-temporal)
+  evql_u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const evql_u32x4*>(p));
   v0 = (u64) q.x | ((u64) q.y << 32);
   v1 = (u64) q.z | ((u64) q.w << 32);
 }
@@ -106,7 +108,7 @@ __device__ __forceinline__ u64 evql_plain64(const u8* image, const u64* pages, u
 __device__ __forceinline__ void evql_plain32_x2(const u8* image, const u64* pages,
                                                 u64 r, u64& v0, u64& v1) {
   const u8* p = image + pages[r >> 17] + ((r & 0x1ffffull) << 2);
-  evql_u32x2 q = *reinterpret_cast<const evql_u32x2*>(p);
+  evql_u32x2 q = __builtin_nontemporal_load(reinterpret_cast<const evql_u32x2*>(p));
   v0 = q.x;
   v1 = q.y;
 }
@@ -118,7 +120,8 @@ __device__ __forceinline__ u64 evql_plain32(const u8* image, const u64* pages, u
 
 // pre-decoded SoA column
 __device__ __forceinline__ void evql_soa_x2(const u64* soa, u64 r, u64& v0, u64& v1) {
-  const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(soa + r);
+  typedef u64 evql_u64x2 __attribute__((ext_vector_type(2)));
+  const evql_u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const evql_u64x2*>(soa + r));
   v0 = q.x;
   v1 = q.y;
 }
