@@ -351,12 +351,14 @@ class Query:
     def fetch_all(self, batch=1024):
         nc = self.column_count()
         types = [self.column_type(i) for i in range(nc)]
-        raws = [b""] * nc
+        chunks = [[] for _ in range(nc)]
         while True:
             n, raw = self.next_batch(batch)
             if n == 0:
                 break
-            raws = [a + b for a, b in zip(raws, raw)]
+            for c, r in zip(chunks, raw):
+                c.append(r)
+        raws = [b"".join(c) for c in chunks]
         cols = [unpack_svector(t, r) for t, r in zip(types, raws)]
         return Result(cols, types, raws)
 

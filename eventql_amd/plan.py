@@ -469,13 +469,14 @@ def unpack_svector(stype, data):
     mv = memoryview(data)
     pos, n = 0, len(mv)
     if stype in (K.T_UINT64, K.T_TIMESTAMP64, K.T_INT64, K.T_FLOAT64):
-        fmt = {K.T_UINT64: "<Q", K.T_TIMESTAMP64: "<Q", K.T_INT64: "<q",
-               K.T_FLOAT64: "<d"}[stype]
-        while pos < n:
-            v = struct.unpack_from(fmt, mv, pos)[0]
-            tag = mv[pos + 8]
-            out.append(None if tag & K.STAG_NULL else v)
-            pos += 9
+        import numpy as np
+        code = {K.T_UINT64: "<u8", K.T_TIMESTAMP64: "<u8", K.T_INT64: "<i8",
+                K.T_FLOAT64: "<f8"}[stype]
+        rec = np.frombuffer(data, dtype=np.dtype([("v", code), ("t", "u1")]))  # 9-byte elements
+        out = rec["v"].tolist()
+        nulls = np.nonzero(rec["t"] & K.STAG_NULL)[0]
+        for i in nulls.tolist():
+            out[i] = None
     elif stype == K.T_BOOL:
         while pos < n:
             out.append(None if mv[pos + 1] & K.STAG_NULL else bool(mv[pos]))

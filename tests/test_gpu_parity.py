@@ -765,6 +765,60 @@ def test_device_generator_matches_host_twin(ctx, tmp_path):
     t.close()
 
 
+def test_full_size_high_cardinality_properties(ctx):
+    """BASELINE config 4 at full size (1.25e8 rows, key uniform in [0, 1e7)): the
+    partitioned path against totals, against itself, and -- group by group on the
+    100,000 smallest keys -- against the LDS path of the same query with a WHERE"""
+    from eventql_amd.plan import Order
+    n, n_keys = 125_000_000, 10_000_000
+    t = ctx.generate(n, "uav", u_mod=n_keys)
+    plan = B.config4(groups_hint=n_keys)
+    q = t.query(plan)
+    assert "evql_part_refine" in q.kernel_source()
+    q.set_order(Order(plan, [(0, False)], limit=100_000))      # 100,000 smallest keys
+    head = q.run()
+    st = q.stats()
+    assert head.nrows == 100_000
+    assert n_keys - 200 < st["num_groups"] <= n_keys and st["rows_passed"] == n
+    keys = [r[0] for r in head.rows()]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys) and keys[-1] < 100_500
+    q.close()
+    # totals through plain global aggregates (register accumulators)
+    tot = t.query(Plan(B.SCHEMA, select=[count(1), sum_(col("a")), sum_(col("v"))])).run().rows()[0]
+    # ... equal the sums over all groups, read through a second top-k ordering
+    q = t.query(plan)
+    q.set_order(Order(plan, [(2, True), (0, False)], limit=50))  # largest counts
+    top = q.run().rows()
+    assert [r[2] for r in top] == sorted((r[2] for r in top), reverse=True)
+    q.close()
+    q = t.query(plan)
+    q.execute()
+    allg = q.fetch_all(1 << 20)       # 1e7 rows through nextBatch
+    assert allg.nrows == st["num_groups"]
+    assert sum(r[2] for r in allg.rows()) == n == tot[0]
+    assert sum(r[1] for r in allg.rows()) == tot[1]
+    sv = sum(r[3] for r in allg.rows())
+    assert abs(sv - tot[2]) <= 1e-9 * abs(tot[2])
+    by_key = {r[0]: r for r in allg.rows()}
+    assert max(r[2] for r in allg.rows()) == top[0][2]
+    q.close()
+    # the same groups through a different code path: WHERE u < 100,000 -> ~1e5
+    # groups, LDS / HBM-atomic path
+    q = t.query(Plan(B.SCHEMA, select=[col("u"), sum_(col("a")), count(1), sum_(col("v"))],
+                     group_by=[col("u")], where=col("u") < 100_000, groups_hint=100_000))
+    assert "evql_part_refine" not in q.kernel_source()
+    small = q.run()
+    assert small.nrows == sum(1 for k in by_key if k < 100_000)
+    for k, sa, c, v in small.rows():
+        r = by_key[k]
+        assert (sa, c) == (r[1], r[2]), k
+        assert abs(v - r[3]) <= 1e-9 * abs(v), k
+    for r_head in head.rows():
+        assert r_head[1:3] == by_key[r_head[0]][1:3]
+    q.close()
+    t.close()
+
+
 def test_full_size_properties(ctx):
     """BASELINE sizes (1e9 rows, config 3): size-independent properties"""
     n = 1_000_000_000
