@@ -227,11 +227,7 @@ evql_table::~evql_table() {
       if (p) hipFree(p);
     }
   }
-  for (auto& kv : materialized) {
-    if (kv.second.d_values) hipFree(kv.second.d_values);
-    if (kv.second.d_tags) hipFree(kv.second.d_tags);
-    if (kv.second.d_strpos) hipFree(kv.second.d_strpos);
-  }
+  // (`materialized` columns free their device arrays themselves)
   for (auto& kv : nested_cache) {
     if (kv.second.d_values) hipFree(kv.second.d_values);
   }
@@ -363,10 +359,10 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
     Status st = scan_string_column(t, c, &m);
     if (!st.ok()) return st;
     m.string_hash = true;
-    uint64_t* d_off = nullptr;
-    uint32_t* d_len = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_off), std::max<uint64_t>(n, 1) * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_len), std::max<uint64_t>(n, 1) * 4));
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint32_t> d_len;
+    HIP_TRY(d_off.alloc(n * 8));
+    HIP_TRY(d_len.alloc(n * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_tags), np));
     HIP_TRY(hipMemsetAsync(m.d_tags, 0, np, s));
     if (n) {
@@ -376,8 +372,6 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
       HIP_TRY(launch_string_hash(t->d_image, t->d_pages[li][0], d_off, d_len, n, m.d_values, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(d_off);
-    hipFree(d_len);
     t->materialized[c.name] = std::move(m);
     if (ca.string_bytes) return upload_string_positions(t, &t->materialized[c.name]);
     return Status();
@@ -386,15 +380,15 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
   // where do defined values come from?
   RtColumn src{};
   src.pages = t->d_pages[li][0];
-  uint64_t* d_dense = nullptr;  // LEB128 decoded
+  DevBuf<uint64_t> d_dense;  // LEB128 decoded (nullable columns only)
   uint64_t nvalues = n;
-  uint64_t* d_tiles = nullptr;
+  DevBuf<uint64_t> d_tiles;
   const uint64_t ntiles = (n + kDecodeTile - 1) / kDecodeTile;
 
   if (c.dlevel_max > 0) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_tags), np));
     HIP_TRY(hipMemsetAsync(m.d_tags, 1, np, s));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tiles), (ntiles + 1) * 8));
+    HIP_TRY(d_tiles.alloc((ntiles + 1) * 8));
     uint32_t maxv = 0;
     if (!c.dlevel_pages.empty()) {
       HIP_TRY(hipMemcpy(&maxv, t->d_image + c.dlevel_pages[0].offset, 4, hipMemcpyDeviceToHost));
@@ -402,7 +396,7 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
     const uint32_t dbits = c.dlevel_pages.empty() ? 0 : bitpack_width(maxv);
     HIP_TRY(launch_dlevel_tags(t->d_image, t->d_pages[li][2], dbits, c.dlevel_max, n, m.d_tags,
                                d_tiles, s));
-    uint64_t* d_total = d_tiles + ntiles;
+    uint64_t* d_total = d_tiles.p + ntiles;
     HIP_TRY(launch_exclusive_scan(d_tiles, ntiles, d_total, s));
     HIP_TRY(hipMemcpyAsync(&nvalues, d_total, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -429,19 +423,24 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
     case ColumnEncoding::UINT64_LEB128: {
       const uint64_t nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
       const uint64_t nchunks = (nbytes + kLebChunk - 1) / kLebChunk;
-      uint64_t* d_chunks = nullptr;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_chunks), (nchunks + 1) * 8));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), std::max<uint64_t>(nvalues, 1) * 8));
+      DevBuf<uint64_t> d_chunks;
+      HIP_TRY(d_chunks.alloc((nchunks + 1) * 8));
+      // a non-nullable column decodes straight into its SoA array; a nullable one
+      // into a dense array that the expansion below reads by value index
+      uint64_t* dst = m.d_values;
+      if (c.dlevel_max > 0) {
+        HIP_TRY(d_dense.alloc(nvalues * 8));
+        dst = d_dense;
+      }
       if (nchunks) {
         HIP_TRY(launch_leb128_count(t->d_image, t->d_pages[li][0], nbytes, d_chunks, s));
         HIP_TRY(launch_exclusive_scan(d_chunks, nchunks, nullptr, s));
-        HIP_TRY(launch_leb128_decode(t->d_image, t->d_pages[li][0], nbytes, d_chunks, nvalues,
-                                     d_dense, s));
+        HIP_TRY(launch_leb128_decode(t->d_image, t->d_pages[li][0], nbytes, d_chunks, nvalues, dst,
+                                     s));
       }
       HIP_TRY(hipStreamSynchronize(s));
-      hipFree(d_chunks);
       src.mode = ColAccess::SOA;
-      src.soa = d_dense;
+      src.soa = dst;
       break;
     }
     default:
@@ -451,15 +450,6 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
   if (c.dlevel_max > 0) {
     HIP_TRY(launch_expand_nullable(t->d_image, src, m.d_tags, d_tiles, n, m.d_values, s));
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(d_tiles);
-    if (d_dense) hipFree(d_dense);
-  } else {
-    // non-nullable LEB128: the dense decode already is the SoA column
-    if (d_dense) {
-      HIP_TRY(hipMemcpyAsync(m.d_values, d_dense, n * 8, hipMemcpyDeviceToDevice, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      hipFree(d_dense);
-    }
   }
   t->materialized[c.name] = std::move(m);
   return Status();
@@ -560,8 +550,8 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
   // a column without definition levels is required and top-level: one slot per record
   if (c.dlevel_max == 0) nslots_flat = t->layout.num_rows;
   uint64_t cap = nslots_flat;
-  uint8_t* d_tags = nullptr;
-  uint64_t* d_tiles = nullptr;
+  DevBuf<uint8_t> d_tags;
+  DevBuf<uint64_t> d_tiles;
   uint64_t nvalues = nslots_flat;
   if (c.dlevel_max > 0) {
     uint32_t dbits = 0;
@@ -571,13 +561,13 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
   }
   const uint64_t capp = padded_rows(cap);
   const uint64_t ntiles = (cap + kDecodeTile - 1) / kDecodeTile;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tags), capp));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tiles), (ntiles + 2) * 8));
+  HIP_TRY(d_tags.alloc(capp));
+  HIP_TRY(d_tiles.alloc((ntiles + 2) * 8));
   if (c.dlevel_max > 0) {
     uint32_t dbits = 0;
     stream_bits(t, c.dlevel_pages, &dbits);
-    uint8_t* d_lv = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_lv), capp));
+    DevBuf<uint8_t> d_lv;
+    HIP_TRY(d_lv.alloc(capp));
     HIP_TRY(hipMemsetAsync(d_lv, 0xff, capp, s));
     if (dbits == 0) {
       // every slot has definition level 0
@@ -593,11 +583,10 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
       HIP_TRY(launch_level_decode(la, s));
     }
     HIP_TRY(launch_defined_from_levels(d_lv, c.dlevel_max, cap, d_tags, d_tiles, s));
-    uint64_t* d_total = d_tiles + ntiles;
+    uint64_t* d_total = d_tiles.p + ntiles;
     HIP_TRY(launch_exclusive_scan(d_tiles, ntiles, d_total, s));
     HIP_TRY(hipMemcpyAsync(&nvalues, d_total, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(d_lv);
   } else {
     HIP_TRY(hipMemsetAsync(d_tags, 0, capp, s));
     std::vector<uint64_t> offs(ntiles + 1);
@@ -607,7 +596,7 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
   }
   RtColumn src{};
   src.pages = t->d_pages[li][0];
-  uint64_t* d_dense = nullptr;
+  DevBuf<uint64_t> d_dense;
   switch (c.storage_type) {
     case ColumnEncoding::UINT64_PLAIN:
     case ColumnEncoding::FLOAT_IEEE754:
@@ -626,9 +615,9 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
     case ColumnEncoding::UINT64_LEB128: {
       const uint64_t nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
       const uint64_t nchunks = (nbytes + kLebChunk - 1) / kLebChunk;
-      uint64_t* d_chunks = nullptr;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_chunks), (nchunks + 1) * 8));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), std::max<uint64_t>(nvalues, 1) * 8));
+      DevBuf<uint64_t> d_chunks;
+      HIP_TRY(d_chunks.alloc((nchunks + 1) * 8));
+      HIP_TRY(d_dense.alloc(nvalues * 8));
       if (nchunks) {
         HIP_TRY(launch_leb128_count(t->d_image, t->d_pages[li][0], nbytes, d_chunks, s));
         HIP_TRY(launch_exclusive_scan(d_chunks, nchunks, nullptr, s));
@@ -636,7 +625,6 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
                                      d_dense, s));
       }
       HIP_TRY(hipStreamSynchronize(s));
-      hipFree(d_chunks);
       src.mode = ColAccess::SOA;
       src.soa = d_dense;
       break;
@@ -644,15 +632,12 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
     default:
       return Status::error(EVQL_ENOTSUP, "unsupported nested column encoding");
   }
-  uint64_t* d_vals = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vals), capp * 8));
+  DevBuf<uint64_t> d_vals;
+  HIP_TRY(d_vals.alloc(capp * 8));
   HIP_TRY(hipMemsetAsync(d_vals, 0, capp * 8, s));
   HIP_TRY(launch_expand_nullable(t->d_image, src, d_tags, d_tiles, cap, d_vals, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipFree(d_tags);
-  hipFree(d_tiles);
-  if (d_dense) hipFree(d_dense);
-  *out_vals = d_vals;
+  *out_vals = d_vals.release();
   *out_cap = cap;
   return Status();
 }
@@ -692,9 +677,15 @@ static Status materialize_nested(evql_query* q) {
     }
   }
   uint64_t nflat = nrec;
-  uint8_t* d_leaf_levels = nullptr;
+  DevBuf<uint8_t> d_leaf_levels;
   std::vector<uint32_t> thr_levels;       // distinct parent rlevel_max values
-  std::vector<uint64_t*> thr_offsets;     // scanned per-tile counts per threshold
+  struct OwnedList {                       // scanned per-tile counts per threshold
+    std::vector<uint64_t*> v;
+    ~OwnedList() {
+      for (auto* p : v) hipFree(p);
+    }
+  } thr_offsets_owner;
+  std::vector<uint64_t*>& thr_offsets = thr_offsets_owner.v;
   if (lc.rlevel_max > 0) {
     uint32_t rbits = 0;
     Status st = stream_bits(t, lc.rlevel_pages, &rbits);
@@ -713,7 +704,7 @@ static Status materialize_nested(evql_query* q) {
     if (thr_levels.size() > 4) {
       return Status::error(EVQL_ENOTSUP, "more than four repetition depths in one nested scan");
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_leaf_levels), capp));
+    HIP_TRY(d_leaf_levels.alloc(capp));
     HIP_TRY(hipMemsetAsync(d_leaf_levels, 0xff, capp, s));
     LevelDecodeArgs la{};
     la.image = t->d_image;
@@ -737,13 +728,12 @@ static Status materialize_nested(evql_query* q) {
       HIP_TRY(launch_exclusive_scan(thr_offsets[k], ntiles, nullptr, s));
     }
     // number of real slots = start of record number `nrec`
-    uint64_t* d_n = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_n), 8));
+    DevBuf<uint64_t> d_n;
+    HIP_TRY(d_n.alloc(8));
     HIP_TRY(hipMemcpyAsync(d_n, &cap, 8, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_find_nth(d_leaf_levels, thr_offsets[0], cap, 0, nrec, d_n, s));
     HIP_TRY(hipMemcpyAsync(&nflat, d_n, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(d_n);
   }
   q->nested_rows = nflat;
   const uint64_t flatp = padded_rows(nflat);
@@ -766,34 +756,30 @@ static Status materialize_nested(evql_query* q) {
       }
     }
     const ColumnLayout& c = t->layout.columns[li];
-    uint64_t* d_vals = nullptr;
+    DevBuf<uint64_t> d_vals;
     uint64_t cap = 0;
-    Status st = nested_slot_values(t, li, nflat, &d_vals, &cap);
+    Status st = nested_slot_values(t, li, nflat, &d_vals.p, &cap);
     if (!st.ok()) return st;
     if (c.rlevel_max >= lc.rlevel_max) {
       if (padded_rows(cap) < flatp) {
         // level streams shorter than the leaf's: not the same ancestor chain
-        hipFree(d_vals);
         return Status::error(EVQL_ENOTSUP, "nested columns from different repeated groups");
       }
       q->nested_flat[i] = d_vals;
-      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_vals, nflat};
+      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_vals.release(), nflat};
     } else {
       size_t k = 0;
       while (thr_levels[k] != c.rlevel_max) ++k;
-      uint64_t* d_flat = nullptr;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_flat), flatp * 8));
+      DevBuf<uint64_t> d_flat;
+      HIP_TRY(d_flat.alloc(flatp * 8));
       HIP_TRY(hipMemsetAsync(d_flat, 0, flatp * 8, s));
       HIP_TRY(launch_flatten_parent(d_leaf_levels, thr_offsets[k], c.rlevel_max, nflat, d_vals,
                                     d_flat, s));
       HIP_TRY(hipStreamSynchronize(s));
-      hipFree(d_vals);
       q->nested_flat[i] = d_flat;
-      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_flat, nflat};
+      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_flat.release(), nflat};
     }
   }
-  if (d_leaf_levels) hipFree(d_leaf_levels);
-  for (auto* p : thr_offsets) hipFree(p);
   return Status();
 }
 
@@ -1165,14 +1151,14 @@ static Status fetch_results(evql_query* q) {
   // small results (the usual case) reuse a per-query 1 MiB buffer: no allocation
   // inside a step
   const size_t kSmallRec = 1 << 20;
-  bool rec_owned = true;
+  DevBuf<uint64_t> rec_own;  // records that do not fit the small buffer
   if (n) {
     if (n * (nwords + 1) * 8 <= kSmallRec) {
       if (!q->d_small_rec) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_small_rec), kSmallRec));
       d_rec = q->d_small_rec;
-      rec_owned = false;
     } else {
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec), n * (nwords + 1) * 8));
+      HIP_TRY(rec_own.alloc(n * (nwords + 1) * 8));
+      d_rec = rec_own;
     }
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
     HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec, n, d_cnt, s));
@@ -1184,11 +1170,11 @@ static Status fetch_results(evql_query* q) {
   if (n && !q->order.empty() && q->has_limit && want < n) {
     uint64_t m = 0;
     if (want > 0) {
-      uint64_t *d_keys = nullptr, *d_hist = nullptr, *d_idx = nullptr, *d_ctr = nullptr;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_keys), n * 8));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_hist), 256 * 8));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_idx), n * 8));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ctr), 3 * 8));
+      DevBuf<uint64_t> d_keys, d_hist, d_idx, d_ctr;
+      HIP_TRY(d_keys.alloc(n * 8));
+      HIP_TRY(d_hist.alloc(256 * 8));
+      HIP_TRY(d_idx.alloc(n * 8));
+      HIP_TRY(d_ctr.alloc(3 * 8));
       OrderKeyArgs ka = q->order_key;
       ka.records = d_rec;
       ka.record_words = nwords + 1;
@@ -1215,17 +1201,13 @@ static Status fetch_results(evql_query* q) {
       HIP_TRY(hipMemcpyAsync(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       m = ctr[2];
-      uint64_t* d_rec2 = nullptr;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rec2), std::max<uint64_t>(m, 1) * (nwords + 1) * 8));
+      DevBuf<uint64_t> d_rec2;
+      HIP_TRY(d_rec2.alloc(m * (nwords + 1) * 8));
       HIP_TRY(launch_gather_records(d_rec, nwords + 1, d_idx, m, d_rec2, s));
       HIP_TRY(hipStreamSynchronize(s));
-      if (rec_owned) hipFree(d_rec);
-      d_rec = d_rec2;
-      rec_owned = true;
-      hipFree(d_keys);
-      hipFree(d_hist);
-      hipFree(d_idx);
-      hipFree(d_ctr);
+      rec_own.reset();
+      rec_own.p = d_rec2.release();
+      d_rec = rec_own;
     }
     n = m;
   }
@@ -1276,14 +1258,13 @@ static Status fetch_results(evql_query* q) {
         rc[c].tags = m.d_tags;
       }
     }
-    uint64_t* d_rows = nullptr;
-    RtColumn* d_cols = nullptr;
-    uint64_t* d_vals = nullptr;
-    uint8_t* d_tags = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rows), n * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cols), nc * sizeof(RtColumn)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_vals), n * nc * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_tags), n * nc));
+    DevBuf<uint64_t> d_rows, d_vals;
+    DevBuf<RtColumn> d_cols;
+    DevBuf<uint8_t> d_tags;
+    HIP_TRY(d_rows.alloc(n * 8));
+    HIP_TRY(d_cols.alloc(nc * sizeof(RtColumn)));
+    HIP_TRY(d_vals.alloc(n * nc * 8));
+    HIP_TRY(d_tags.alloc(n * nc));
     HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_cols, rc.data(), nc * sizeof(RtColumn), hipMemcpyHostToDevice, s));
     HIP_TRY(launch_gather_rows(t->d_image, d_cols, nc, d_rows, n, d_vals, d_tags, s));
@@ -1292,12 +1273,7 @@ static Status fetch_results(evql_query* q) {
     HIP_TRY(hipMemcpyAsync(q->first_vals.data(), d_vals, n * nc * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(q->first_tags.data(), d_tags, n * nc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    hipFree(d_rows);
-    hipFree(d_cols);
-    hipFree(d_vals);
-    hipFree(d_tags);
   }
-  if (d_rec && rec_owned) hipFree(d_rec);
   q->stats.num_groups = total_groups;
   q->emit_pos = 0;
   q->executed = true;

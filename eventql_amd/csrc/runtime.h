@@ -83,7 +83,34 @@ struct evql_ctx {
   std::map<std::string, evql::Module> modules;  // by source fingerprint
 };
 
-// a decoded-to-SoA column cached on the table
+namespace evql {
+// owning device pointer for temporaries: freed on every exit path (HIP_TRY returns
+// early on errors)
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { reset(); }
+  hipError_t alloc(size_t bytes) {
+    reset();
+    return hipMalloc(reinterpret_cast<void**>(&p), bytes ? bytes : 1);
+  }
+  void reset() {
+    if (p) hipFree(p);
+    p = nullptr;
+  }
+  T* release() {
+    T* r = p;
+    p = nullptr;
+    return r;
+  }
+  operator T*() const { return p; }
+};
+}  // namespace evql
+
+// a decoded-to-SoA column cached on the table (owns its device arrays)
 struct MaterializedColumn {
   uint64_t* d_values = nullptr;
   uint8_t* d_tags = nullptr;
@@ -94,6 +121,26 @@ struct MaterializedColumn {
   std::vector<uint64_t> str_off;
   std::vector<uint32_t> str_len;
   std::vector<uint8_t> str_tag;
+
+  MaterializedColumn() = default;
+  MaterializedColumn(const MaterializedColumn&) = delete;
+  MaterializedColumn& operator=(const MaterializedColumn&) = delete;
+  MaterializedColumn(MaterializedColumn&& o) noexcept { *this = std::move(o); }
+  MaterializedColumn& operator=(MaterializedColumn&& o) noexcept {
+    std::swap(d_values, o.d_values);
+    std::swap(d_tags, o.d_tags);
+    std::swap(d_strpos, o.d_strpos);
+    std::swap(string_hash, o.string_hash);
+    str_off.swap(o.str_off);
+    str_len.swap(o.str_len);
+    str_tag.swap(o.str_tag);
+    return *this;
+  }
+  ~MaterializedColumn() {
+    if (d_values) hipFree(d_values);
+    if (d_tags) hipFree(d_tags);
+    if (d_strpos) hipFree(d_strpos);
+  }
 };
 
 struct evql_table {
