@@ -5,6 +5,7 @@ Two tables: the mixed-encoding table of the parity tests, and a table whose
 bit-packed / plain / LEB128 columns span their full value ranges (values next to
 2^17, 2^24, 2^31, 2^32, 2^64), where range-dependent code generation (narrowed
 division, shifts, wrap-around) shows."""
+import os
 import random
 
 import numpy as np
@@ -17,6 +18,9 @@ import oracle_lib as O
 import tables as T
 
 pytestmark = pytest.mark.gpu
+
+# EVQL_FUZZ_FROM / EVQL_FUZZ_TO widen the seed range for one-off soak runs
+SEEDS = range(int(os.environ.get("EVQL_FUZZ_FROM", "0")), int(os.environ.get("EVQL_FUZZ_TO", "60")))
 
 
 class Gen:
@@ -196,7 +200,7 @@ def mixed(ctx):
     t.close()
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_plan(mixed, seed):
     t, img = mixed
     g = Gen(seed, **MIXED)
@@ -260,7 +264,7 @@ class NestedGen(Gen):
         return kw
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_nested_plan(nested, seed):
     N, items, fixture = _nested_gens()
     (ti, img_items), (tf, img_fix) = nested
@@ -330,7 +334,7 @@ def ranges(ctx):
     t.close()
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_plan_full_range_columns(ranges, seed):
     t, img = ranges
     g = Gen(1000 + seed, **RANGES)
