@@ -54,7 +54,7 @@ INSTANCE_ACCUMULATE = 1
 INSTANCE_GET = 2
 
 MODE_FINAL, MODE_PARTIAL = 0, 1
-SCAN_FLAT, SCAN_NESTED = 0, 1
+SCAN_FLAT, SCAN_NESTED, SCAN_NESTED_WITHIN_RECORD = 0, 1, 2
 
 
 class Instr(C.Structure):

@@ -650,6 +650,57 @@ __global__ void __launch_bounds__(kBlock) k_flatten_parent(const u8* leaf_levels
   }
 }
 
+// AGGREGATE_WITHIN_RECORD_FLAT: every thread walks 8 consecutive flattened rows,
+// keeps the running per-record sums in registers and adds them to the record's
+// output words when the record changes (rows of one record are adjacent, so a
+// thread issues ~1 atomic per aggregate and record it touches)
+__global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
+  const u64 tile = blockIdx.x;
+  const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  u64 packed = 0;
+  u64 idx = s0;  // records started before row s0
+  if (a.leaf_levels) {
+    packed = *reinterpret_cast<const u64*>(a.leaf_levels + s0);
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cnt += (((packed >> (8 * j)) & 0xff) == 0 && s0 + j < a.nflat) ? 1 : 0;
+    }
+    u32 total;
+    idx = a.rec_offsets[tile] + block_excl_scan(cnt, &total);
+  }
+  u64 acc[kMaxWithinAggs];
+#pragma unroll
+  for (u32 e = 0; e < kMaxWithinAggs; ++e) acc[e] = 0;
+  auto flush = [&](u64 rec) {
+    if (rec >= a.nrec) return;
+#pragma unroll
+    for (u32 e = 0; e < kMaxWithinAggs; ++e) {
+      if (e < a.n && acc[e]) atomicAdd(reinterpret_cast<unsigned long long*>(a.out[e] + rec),
+                                       (unsigned long long) acc[e]);
+      acc[e] = 0;
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u64 s = s0 + j;
+    if (s < a.nflat) {
+      const u32 lvl = (u32) ((packed >> (8 * j)) & 0xff);
+      if (lvl == 0) {
+        if (j > 0 && idx > 0) flush(idx - 1);
+        ++idx;
+      }
+#pragma unroll
+      for (u32 e = 0; e < kMaxWithinAggs; ++e) {
+        if (e < a.n && a.level[e] >= lvl) {
+          acc[e] += a.is_count[e] ? 1ull : (a.src[e] ? a.src[e][s] : a.lit[e]);
+        }
+      }
+    }
+  }
+  if (idx > 0) flush(idx - 1);
+}
+
 // tags (0 defined / 1 undefined) of a nested column from decoded level bytes
 __global__ void __launch_bounds__(kBlock) k_defined_from_levels(const u8* dlevels, u32 dmax,
                                                                 u64 nslots, u8* tags,
@@ -798,6 +849,13 @@ hipError_t launch_flatten_parent(const uint8_t* leaf_levels, const uint64_t* til
   if (ntiles == 0) return hipSuccess;
   hipLaunchKernelGGL(k_flatten_parent, dim3((unsigned) ntiles), dim3(kBlock), 0, s, leaf_levels,
                      (const u64*) tile_offsets, thr, (u64) nflat, (const u64*) vals, (u64*) flat);
+  return hipGetLastError();
+}
+
+hipError_t launch_within_record(const WithinRecordArgs& a, hipStream_t s) {
+  const u64 ntiles = (a.nflat + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_within_record, dim3((unsigned) ntiles), dim3(kBlock), 0, s, a);
   return hipGetLastError();
 }
 

@@ -524,7 +524,9 @@ int evql_query_next_batch(evql_query_t* q, size_t max_rows, evql_column_buf_t* c
 int evql_query_stats(const evql_query_t* q, evql_query_stats_t* out) {
   *out = q->stats;
   uint64_t bytes = 0;
-  for (const auto& c : q->kp.cols) bytes += q->table->payload_bytes[c.layout_index];
+  for (const auto& c : q->within_record ? q->wr_cols : q->kp.cols) {
+    bytes += q->table->payload_bytes[c.layout_index];
+  }
   // scaled to the scanned row range; + result bytes (key + 8 B per aggregate)
   const uint64_t nrows = q->table->layout.num_rows;
   if (nrows && q->stats.rows_scanned != nrows) {

@@ -124,9 +124,15 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     return Status::error(EVQL_ENOTSUP, m);
   };
 
-  const bool nested = plan->scan_mode == EVQL_SCAN_NESTED;
+  const bool within = plan->scan_mode == EVQL_SCAN_NESTED_WITHIN_RECORD;
+  const bool nested = plan->scan_mode == EVQL_SCAN_NESTED || within;
   if (plan->scan_mode != EVQL_SCAN_FLAT && !nested) return Status::error(EVQL_EARG, "bad scan mode");
   q->nested = nested;
+  q->within_record = within;
+  if (within && plan->where) return unsup("WHERE in a WITHIN RECORD scan is not lowered");
+  if (within && plan->n_scan_select == 0) {
+    return Status::error(EVQL_EARG, "WITHIN RECORD scan without a scan select list");
+  }
   if (nested && plan->row_filter_bits) return unsup("row filter on a nested scan");
   if (nested && (plan->row_begin || plan->row_end)) return unsup("row range on a nested scan");
   if (plan->n_scan_columns > EVQL_MAX_COLS_HOST) return unsup("too many scan columns");
@@ -261,7 +267,69 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
   }
   q->scan_select.resize(plan->n_scan_select);
   std::vector<ExprPtr> scan_out;
-  for (uint32_t i = 0; i < plan->n_scan_select; ++i) {
+  if (within) {
+    // the record scan reads the plan's columns; the operators above it read one
+    // per-record value per scan select expression
+    q->wr_cols.swap(kp.cols);
+    // (without columns the reference takes fetchNextWithoutColumns and calls the
+    // aggregates' `get` on a null instance, CSTableScan.cc:567-577)
+    if (q->wr_cols.empty()) return Status::error(EVQL_EARG, "WITHIN RECORD scan without columns");
+  }
+  for (uint32_t i = 0; i < plan->n_scan_select && within; ++i) {
+    LoweredProgram& lp = q->scan_select[i];
+    err = lower_program(plan->scan_select[i], &lp, &u);
+    if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
+    if (!lp.is_aggregate || lp.call->kind != Expr::AGG_GET) {
+      return unsup("WITHIN RECORD select expressions other than a bare aggregate");
+    }
+    evql_query::WithinAgg w;
+    ExprPtr arg;
+    switch (lp.aggregate_fn) {
+      case EVQL_AGG_COUNT:
+        w.is_count = true;
+        if (lp.acc_args.size() == 1) {
+          arg = lp.acc_args[0];
+          if (arg->kind == Expr::CALL && arg->family == EVQL_FAM_TO_NIL) arg = arg->args[0];
+        }
+        break;
+      case EVQL_AGG_SUM_UINT64:
+      case EVQL_AGG_SUM_INT64:
+        if (lp.acc_args.size() != 1) return Status::error(EVQL_EARG, "aggregate arity");
+        arg = lp.acc_args[0];
+        break;
+      default:
+        return unsup("WITHIN RECORD aggregates other than count / integer sum");
+    }
+    if (arg && arg->kind == Expr::INPUT) {
+      if (arg->input >= q->wr_cols.size()) return Status::error(EVQL_EARG, "bad input index");
+      const ColAccess& c = q->wr_cols[arg->input];
+      if (!w.is_count && c.stype != EVQL_T_UINT64) {
+        return unsup("WITHIN RECORD sum over a column that is not UINT64");
+      }
+      w.col = int(arg->input);
+      w.level = layout.columns[c.layout_index].rlevel_max;
+    } else if (arg && arg->kind == Expr::LITERAL) {
+      if (!w.is_count && (arg->lit_tag != 0 ||
+                          (arg->type != EVQL_T_UINT64 && arg->type != EVQL_T_INT64))) {
+        return unsup("WITHIN RECORD sum over a literal that is not an integer");
+      }
+      w.lit = arg->lit_bits;
+    } else if (arg) {
+      return unsup("WITHIN RECORD aggregates over expressions are not lowered");
+    }
+    q->wr_aggs.push_back(w);
+    ColAccess v;
+    v.name = "$" + std::to_string(i);
+    v.stype = lp.return_type;
+    v.mode = ColAccess::SOA;
+    kp.cols.push_back(v);
+    auto in = std::make_shared<Expr>();
+    in->kind = Expr::INPUT;
+    in->type = lp.return_type;
+    in->input = i;
+    scan_out.push_back(in);
+  }
+  for (uint32_t i = 0; i < plan->n_scan_select && !within; ++i) {
     err = lower_program(plan->scan_select[i], &q->scan_select[i], &u);
     if (!err.empty()) return u ? unsup(err) : Status::error(EVQL_EARG, err);
     if (q->scan_select[i].is_aggregate) return unsup("aggregate in the scan select list");

@@ -642,15 +642,29 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
   return Status();
 }
 
-static Status materialize_nested(evql_query* q) {
+// the leaf's decoded repetition levels and the scanned per-tile counts of its
+// level-0 slots (= records started), kept for the WITHIN RECORD reduction
+struct LeafLevels {
+  DevBuf<uint8_t> levels;
+  DevBuf<uint64_t> rec_offsets;
+};
+
+// flattens `cols` (all of one ancestor chain) to one value per leaf slot:
+// (*flat)[i] is borrowed from the table's nested cache
+static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& cols,
+                                 std::vector<uint64_t*>* flat_out, uint64_t* nrows_out,
+                                 LeafLevels* keep) {
   evql_table* t = q->table;
   evql_ctx* ctx = q->ctx;
   hipStream_t s = ctx->stream;
-  KernelPlan& kp = q->kp;
+  struct {
+    const std::vector<ColAccess>& cols;
+  } kp{cols};
+  std::vector<uint64_t*>& nested_flat = *flat_out;
   const uint64_t nrec = t->layout.num_rows;
-  q->nested_flat.assign(kp.cols.size(), nullptr);
+  nested_flat.assign(kp.cols.size(), nullptr);
   if (kp.cols.empty()) {
-    q->nested_rows = nrec;  // fetchNextWithoutColumns: one row per record
+    *nrows_out = nrec;  // fetchNextWithoutColumns: one row per record
     return Status();
   }
   // leaf = deepest referenced column
@@ -665,13 +679,13 @@ static Status materialize_nested(evql_query* q) {
   const int leaf_li = kp.cols[leaf].layout_index;
   {
     // every column already flattened for this leaf by an earlier operator?
-    bool all = true;
+    bool all = keep == nullptr;
     for (const auto& c : kp.cols) all = all && t->nested_cache.count({c.layout_index, leaf_li});
     if (all) {
       for (size_t i = 0; i < kp.cols.size(); ++i) {
         const auto& e = t->nested_cache[{kp.cols[i].layout_index, leaf_li}];
-        q->nested_flat[i] = e.d_values;
-        q->nested_rows = e.nflat;
+        nested_flat[i] = e.d_values;
+        *nrows_out = e.nflat;
       }
       return Status();
     }
@@ -735,14 +749,15 @@ static Status materialize_nested(evql_query* q) {
     HIP_TRY(hipMemcpyAsync(&nflat, d_n, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
-  q->nested_rows = nflat;
+  *nrows_out = nflat;
+  const uint8_t* leaf_levels = d_leaf_levels.p;
   const uint64_t flatp = padded_rows(nflat);
   for (size_t i = 0; i < kp.cols.size(); ++i) {
     // the same column referenced twice shares one buffer
     bool shared = false;
     for (size_t j = 0; j < i; ++j) {
       if (kp.cols[j].layout_index == kp.cols[i].layout_index) {
-        q->nested_flat[i] = q->nested_flat[j];
+        nested_flat[i] = nested_flat[j];
         shared = true;
       }
     }
@@ -751,7 +766,7 @@ static Status materialize_nested(evql_query* q) {
     {
       auto hit = t->nested_cache.find({li, leaf_li});
       if (hit != t->nested_cache.end()) {
-        q->nested_flat[i] = hit->second.d_values;
+        nested_flat[i] = hit->second.d_values;
         continue;
       }
     }
@@ -765,7 +780,7 @@ static Status materialize_nested(evql_query* q) {
         // level streams shorter than the leaf's: not the same ancestor chain
         return Status::error(EVQL_ENOTSUP, "nested columns from different repeated groups");
       }
-      q->nested_flat[i] = d_vals;
+      nested_flat[i] = d_vals;
       t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_vals.release(), nflat};
     } else {
       size_t k = 0;
@@ -773,13 +788,62 @@ static Status materialize_nested(evql_query* q) {
       DevBuf<uint64_t> d_flat;
       HIP_TRY(d_flat.alloc(flatp * 8));
       HIP_TRY(hipMemsetAsync(d_flat, 0, flatp * 8, s));
-      HIP_TRY(launch_flatten_parent(d_leaf_levels, thr_offsets[k], c.rlevel_max, nflat, d_vals,
+      HIP_TRY(launch_flatten_parent(leaf_levels, thr_offsets[k], c.rlevel_max, nflat, d_vals,
                                     d_flat, s));
       HIP_TRY(hipStreamSynchronize(s));
-      q->nested_flat[i] = d_flat;
+      nested_flat[i] = d_flat;
       t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_flat.release(), nflat};
     }
   }
+  if (keep && lc.rlevel_max > 0) {
+    keep->levels.p = d_leaf_levels.release();
+    keep->rec_offsets.p = thr_offsets[0];  // threshold 0 comes first
+    thr_offsets[0] = nullptr;
+  }
+  return Status();
+}
+
+// CSTableScan with AGGREGATE_WITHIN_RECORD_FLAT (CSTableScan.cc:440-487): one
+// output row per record holding the scan select list's aggregates over the
+// record's flattened rows.  select_list_[i] accumulates on the rows whose fetch
+// level is <= its rep_level (:442); with every column on one ancestor chain the
+// fetch level of a row is the leaf's repetition level of that slot.
+static Status materialize_within_record(evql_query* q) {
+  evql_table* t = q->table;
+  hipStream_t s = q->ctx->stream;
+  const uint64_t nrec = t->layout.num_rows;
+  if (q->wr_aggs.size() > kMaxWithinAggs) {
+    return Status::error(EVQL_ENOTSUP, "too many WITHIN RECORD aggregates");
+  }
+  std::vector<uint64_t*> flat;
+  uint64_t nflat = 0;
+  LeafLevels leaf;
+  Status st = materialize_nested(q, q->wr_cols, &flat, &nflat, &leaf);
+  if (!st.ok()) return st;
+  WithinRecordArgs a{};
+  a.leaf_levels = leaf.levels.p;
+  a.rec_offsets = leaf.rec_offsets.p;
+  a.nflat = nflat;
+  a.nrec = nrec;
+  a.n = uint32_t(q->wr_aggs.size());
+  const uint64_t recp = padded_rows(nrec);
+  q->nested_flat.assign(q->wr_aggs.size(), nullptr);
+  for (size_t e = 0; e < q->wr_aggs.size(); ++e) {
+    const evql_query::WithinAgg& w = q->wr_aggs[e];
+    DevBuf<uint64_t> d_out;
+    HIP_TRY(d_out.alloc(recp * 8));
+    HIP_TRY(hipMemsetAsync(d_out, 0, recp * 8, s));
+    a.src[e] = w.col >= 0 ? flat[w.col] : nullptr;
+    a.lit[e] = w.lit;
+    a.level[e] = w.level;
+    a.is_count[e] = w.is_count ? 1 : 0;
+    a.out[e] = d_out;
+    q->nested_flat[e] = d_out;
+    q->nested_owned.push_back(d_out.release());
+  }
+  HIP_TRY(launch_within_record(a, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  q->nested_rows = nrec;
   return Status();
 }
 
@@ -801,8 +865,11 @@ static uint64_t word_identity(int op) {
 Status query_prepare(evql_query* q) {
   evql_table* t = q->table;
   evql_ctx* ctx = q->ctx;
-  if (q->nested) {
-    Status st = materialize_nested(q);
+  if (q->within_record) {
+    Status st = materialize_within_record(q);
+    if (!st.ok()) return st;
+  } else if (q->nested) {
+    Status st = materialize_nested(q, q->kp.cols, &q->nested_flat, &q->nested_rows, nullptr);
     if (!st.ok()) return st;
   }
   // resolve bit widths and materialise SoA columns
@@ -900,8 +967,10 @@ Status query_launch(evql_query* q) {
   a.counters = q->d_counters;
   for (size_t i = 0; i < kp.cols.size(); ++i) {
     const ColAccess& c = kp.cols[i];
-    a.col[i].pages = t->d_pages[c.layout_index][0];
-    a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
+    if (c.layout_index >= 0) {
+      a.col[i].pages = t->d_pages[c.layout_index][0];
+      a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
+    }
     if (q->nested) {
       a.col[i].soa = q->nested_flat[i];
     } else if (c.mode == ColAccess::SOA) {
@@ -1247,7 +1316,7 @@ static Status fetch_results(evql_query* q) {
     std::vector<RtColumn> rc(nc);
     for (uint32_t c = 0; c < nc; ++c) {
       const ColAccess& ca = kp.cols[c];
-      rc[c].pages = t->d_pages[ca.layout_index][0];
+      rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
       rc[c].mode = ca.mode;
       rc[c].bits = ca.bits;
       if (q->nested) {

@@ -193,6 +193,19 @@ struct evql_query {
   uint64_t nested_rows = 0;
   std::vector<uint64_t*> nested_flat;
   std::vector<uint64_t*> nested_owned;
+  // EVQL_SCAN_NESTED_WITHIN_RECORD (CSTableScan.cc:440-487,
+  // AGGREGATE_WITHIN_RECORD_FLAT): the scan select list holds one aggregate per
+  // expression, reduced to one value per record; those per-record arrays are
+  // the `kp.cols` the operators above the scan read.
+  struct WithinAgg {
+    bool is_count = false;
+    int col = -1;        // index into wr_cols, or -1: literal / no argument
+    uint64_t lit = 0;
+    uint32_t level = 0;  // select_list_[i].rep_level
+  };
+  bool within_record = false;
+  std::vector<evql::ColAccess> wr_cols;  // the columns the record scan reads
+  std::vector<WithinAgg> wr_aggs;
   std::string source;
   evql::Module module;
   // execution state

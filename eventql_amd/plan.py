@@ -366,6 +366,8 @@ class Plan:
             _columns_in(where, names)
         for e in list(group_by) + list(select) + list(scan_select or []):
             _columns_in(e, names)
+        # out(i) ("$i") names output column i of an explicit scan select list
+        names = [n for n in names if not n.startswith("$")]
         self.scan_columns = names
         coltypes = {n: self.schema[n] for n in names if n in self.schema}
         for n in names:
@@ -380,7 +382,12 @@ class Plan:
         if scan_select is not None:
             # bare scan: explicit scan select list
             self.scan_select = [CompiledProgram(e, coltypes, colidx) for e in scan_select]
-            out_names = []
+            # group / select expressions above an explicit scan select list (WITHIN
+            # RECORD scans) reference its outputs as out(i)
+            out_names = ["$%d" % i for i in range(len(self.scan_select))]
+            coltypes = dict(coltypes)
+            for i, p in enumerate(self.scan_select):
+                coltypes["$%d" % i] = p.return_type
         else:
             # GROUP BY level: scan output = bare refs in first-use order
             out_names = []

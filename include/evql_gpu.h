@@ -318,7 +318,14 @@ typedef enum {
   EVQL_SCAN_FLAT = 0,
   /* CSTableScan, AggregationStrategy::NO_AGGREGATION (CSTableScan.cc:187-541):
    * Dremel assembly, one row per leaf repetition */
-  EVQL_SCAN_NESTED = 1
+  EVQL_SCAN_NESTED = 1,
+  /* CSTableScan, AggregationStrategy::AGGREGATE_WITHIN_RECORD_FLAT
+   * (`sum(count(x) WITHIN RECORD)`, CSTableScan.cc:440-487): the scan select list
+   * holds AGGREGATE programs; each accumulates over the rows of one record on which
+   * the repetition level permits it (select_list_[i].rep_level >= cur_select_level_,
+   * i.e. once per slot of its column) and the scan emits one row per record.
+   * Lowered for count / sum over a bare column or a literal, without WHERE. */
+  EVQL_SCAN_NESTED_WITHIN_RECORD = 2
 } evql_scan_mode;
 
 typedef struct {

@@ -996,7 +996,7 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
   if (bare_scan) {
     res->ncols = (int) nin;
     res->cols = in;
-    if (pl->scan_mode == EVQL_SCAN_NESTED) {
+    if (pl->scan_mode >= EVQL_SCAN_NESTED) {
       if (nested_scan_all(&sc, in, &res->nrows)) failed = 1;
     } else {
       for (;;) {
@@ -1017,7 +1017,7 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
     }
     svec_t* nested_all = NULL;
     uint64_t nested_rows = 0, nested_pos = 0;
-    if (pl->scan_mode == EVQL_SCAN_NESTED) {
+    if (pl->scan_mode >= EVQL_SCAN_NESTED) {
       if (nested_scan_all(&sc, in, &nested_rows)) failed = 1;
       nested_all = in;
     }
@@ -1025,7 +1025,7 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
     int first_nested = 1;
     while (!failed) {
       size_t n = 0;
-      if (pl->scan_mode == EVQL_SCAN_NESTED) {
+      if (pl->scan_mode >= EVQL_SCAN_NESTED) {
         /* the nested scan was materialised in one go; consume it once */
         if (!first_nested) break;
         first_nested = 0;

@@ -116,6 +116,30 @@ def test_compile_string_predicates(built, tmp_path):
     assert ei.value.code == K.EVQL_ENOTSUP
 
 
+def test_compile_within_record_scan(built, tmp_path):
+    """EVQL_SCAN_NESTED_WITHIN_RECORD (CSTableScan.cc:440-487): the operators above
+    the scan read the per-record aggregates as `$i`; only bare count / integer sum
+    over a column or literal are lowered"""
+    from eventql_amd.plan import out
+    S = {"id": K.T_UINT64, "items.position": K.T_UINT64, "items.price": K.T_UINT64}
+    cols = [dict(name="id", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+            dict(name="items.position", logical_type=K.COL_UNSIGNED_INT,
+                 storage_type=K.ENC_UINT32_PLAIN, rlevel_max=1, dlevel_max=1),
+            dict(name="items.price", logical_type=K.COL_UNSIGNED_INT,
+                 storage_type=K.ENC_UINT64_PLAIN, rlevel_max=1, dlevel_max=1)]
+    inner = [count(col("items.position")), sum_(col("items.price")), count(1), sum_(col("id"))]
+    plan = Plan(S, scan_select=inner, select=[out(0), count(1), sum_(out(1)), sum_(out(3))],
+                group_by=[out(0)], scan_mode=K.SCAN_NESTED_WITHIN_RECORD)
+    assert E.compile_only(plan, cols, cache_dir=str(tmp_path)) > 4000
+    for bad in (dict(scan_select=[sum_(col("items.price") + 1)], select=[sum_(out(0))]),
+                dict(scan_select=[min_(col("items.price"))], select=[sum_(out(0))]),
+                dict(scan_select=[count(col("id")) + 1], select=[sum_(out(0))]),
+                dict(scan_select=[count(1)], select=[sum_(out(0))], where=col("id") > 3)):
+        with pytest.raises(E.EvqlError) as ei:
+            E.compile_only(Plan(S, scan_mode=K.SCAN_NESTED_WITHIN_RECORD, **bad), cols)
+        assert ei.value.code == K.EVQL_ENOTSUP
+
+
 def test_not_lowerable_plans_are_reported(built):
     S = dict(B.SCHEMA)
     # count_distinct keeps its sets on one device: not in a partial aggregate

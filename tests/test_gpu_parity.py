@@ -645,6 +645,79 @@ def test_nested_scan_synthetic_items(ctx):
     t.close()
 
 
+def test_within_record_scan(ctx):
+    """CSTableScan's AGGREGATE_WITHIN_RECORD_FLAT (CSTableScan.cc:440-487): one row
+    per record of per-record count / sum, consumed by the group-by above it --
+    `select sum(count(x) WITHIN RECORD)` and friends on the reference's fixture
+    (v0.1.0 file and its v0.2.0 re-encoding) and on the synthetic items table"""
+    import nested_tables as N
+    import os
+    from eventql_amd.plan import out
+    WR = K.SCAN_NESTED_WITHIN_RECORD
+    S = N.NESTED_SCHEMA
+    tm = col("time")
+    sq_time = col("event.search_query.time")
+    nitems = col("event.search_query.num_result_items")
+    pos = col("event.search_query.result_items.position")
+    clicked = col("event.search_query.result_items.clicked")
+    cases = [
+        (dict(scan_select=[count(sq_time), sum_(nitems), count(pos), count(1)],
+              select=[sum_(out(0)), sum_(out(1)), sum_(out(2)), sum_(out(3)), count(1)]),
+         [(773, 24793, 24866, 213, 213)]),
+        # per-record item counts as the group key
+        (dict(scan_select=[count(pos), sum_(nitems), sum_(pos), count(clicked)],
+              select=[out(0), count(1), sum_(out(1)), max_(out(2)), min_(out(3))],
+              group_by=[out(0)]), None),
+        (dict(scan_select=[count(sq_time), sum_(tm), sum_(lit(2))],
+              select=[out(0), count(1), sum_(out(1)), sum_(out(2))], group_by=[out(0)]), None),
+        (dict(scan_select=[sum_(tm), count(1)], select=[sum_(out(0)), sum_(out(1))]), None),
+    ]
+    for img in (N.testtbl_v2(), os.path.join(T.GOLDEN, "testtbl.cst")):
+        t = ctx.open_file(img) if isinstance(img, str) else ctx.open_image(img)
+        for kw, known in cases:
+            plan = Plan(S, scan_mode=WR, **kw)
+            exp = O.oracle_run(img, plan)
+            if known is not None:
+                assert exp.rows() == known
+            q = t.query(plan)
+            got = q.run()
+            T.compare_results(got.rows(), exp.rows(), exp.types,
+                              key_cols=len(kw.get("group_by", [])))
+            assert q.stats()["rows_passed"] == 213
+            q.close()
+        t.close()
+    img, st = N.items_table(100_000)
+    t = ctx.open_image(img)
+    S = N.ITEMS_SCHEMA
+    ipos, price, rid = col("items.position"), col("items.price"), col("id")
+    for kw in (dict(scan_select=[count(ipos), sum_(price)],
+                    select=[out(0), count(1), sum_(out(1)), max_(out(1))], group_by=[out(0)]),
+               dict(scan_select=[sum_(price), sum_(ipos), count(1), sum_(rid)],
+                    select=[sum_(out(0)), sum_(out(1)), sum_(out(2)), sum_(out(3))]),
+               dict(scan_select=[sum_(rid), count(rid)],
+                    select=[out(0) % 5, sum_(out(1))], group_by=[out(0) % 5])):
+        plan = Plan(S, scan_mode=WR, **kw)
+        exp = O.oracle_run(img, plan)
+        q = t.query(plan)
+        T.compare_results(q.run().rows(), exp.rows(), exp.types,
+                          key_cols=len(kw.get("group_by", [])))
+        q.close()
+    got = t.query(Plan(S, scan_select=[sum_(price), sum_(ipos)],
+                       select=[sum_(out(0)), sum_(out(1)), count(1)], scan_mode=WR)).run()
+    assert got.rows() == [(st["sum_price"], st["sum_pos"], 100_000)]
+    # a record scan without columns is undefined in the reference (null instance)
+    with pytest.raises(E.EvqlError) as ei:
+        t.query(Plan(S, scan_select=[count(1)], select=[sum_(out(0))], scan_mode=WR))
+    assert ei.value.code == K.EVQL_EARG
+    # not lowered: WHERE, expressions inside the per-record aggregate
+    for bad in (dict(scan_select=[count(1)], select=[sum_(out(0))], where=rid > 5),
+                dict(scan_select=[sum_(price * 2)], select=[sum_(out(0))])):
+        with pytest.raises(E.EvqlError) as ei:
+            t.query(Plan(S, scan_mode=WR, **bad))
+        assert ei.value.code == K.EVQL_ENOTSUP
+    t.close()
+
+
 def _small_table(ctx, cols, specs, n):
     w = E.Writer(specs)
     for s in specs:
