@@ -328,6 +328,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     in->type = lp.return_type;
     in->input = i;
     scan_out.push_back(in);
+    // result emission evaluates the scan select list over the group's first row:
+    // above a record scan that is the per-record value itself
+    lp.call = in;
+    lp.is_aggregate = false;
   }
   for (uint32_t i = 0; i < plan->n_scan_select && !within; ++i) {
     err = lower_program(plan->scan_select[i], &q->scan_select[i], &u);

@@ -283,6 +283,39 @@ def test_random_nested_plan(nested, seed):
     run_case(t, img, schema, kw)
 
 
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_within_record_plan(nested, seed):
+    """AGGREGATE_WITHIN_RECORD_FLAT: a random list of per-record count / sum over
+    columns of every depth (or literals), random operators above it over `$i`"""
+    import random
+    from eventql_amd.plan import count, sum_, col, lit
+    N, items, fixture = _nested_gens()
+    (ti, img_items), (tf, img_fix) = nested
+    which = seed % 2
+    t, img, schema, cols = ((ti, img_items, N.ITEMS_SCHEMA, items) if which == 0 else
+                            (tf, img_fix, N.NESTED_SCHEMA, fixture))
+    r = random.Random(7000 + seed)
+    inner = []
+    for _ in range(r.randint(1, 5)):
+        c = col(r.choice(cols["uint_cols"]))
+        inner.append(r.choice([lambda: count(c), lambda: sum_(c), lambda: count(1),
+                               lambda: sum_(lit(r.choice([1, 3, 1000]))),
+                               lambda: count(col(r.choice(cols["uint_cols"] + cols["bool_cols"])))
+                               ])())
+    # (a record scan needs at least one column)
+    inner.append(count(col(r.choice(cols["uint_cols"]))))
+    outs = ["$%d" % i for i in range(len(inner))]
+    g = Gen(8000 + seed, uint_cols=outs, float_cols=[], bool_cols=[], key_cols=outs,
+            first_cols=outs, lits=[0, 1, 2, 5, 9, 40, 1000])
+    g.flt = lambda depth=0: Lit(g.r.choice([0.0, 1.5, -2.25, 100.0]))
+    kw = g.plan_kwargs([1])
+    kw.pop("row_end", None)
+    kw.pop("where", None)
+    kw["scan_select"] = inner
+    kw["scan_mode"] = K.SCAN_NESTED_WITHIN_RECORD
+    run_case(t, img, schema, kw)
+
+
 # ---- full-range columns -------------------------------------------------------------------
 RANGES_SCHEMA = dict(x17=K.T_UINT64, x24=K.T_UINT64, x31=K.T_UINT64, x32=K.T_UINT64,
                      p32=K.T_UINT64, q64=K.T_UINT64, l64=K.T_UINT64, g=K.T_UINT64,

@@ -671,6 +671,9 @@ def test_within_record_scan(ctx):
         (dict(scan_select=[count(sq_time), sum_(tm), sum_(lit(2))],
               select=[out(0), count(1), sum_(out(1)), sum_(out(2))], group_by=[out(0)]), None),
         (dict(scan_select=[sum_(tm), count(1)], select=[sum_(out(0)), sum_(out(1))]), None),
+        # non-aggregate select expressions read the group's first record
+        (dict(scan_select=[count(sq_time), sum_(nitems), sum_(tm)],
+              select=[out(0), out(1) + 1, out(2), count(1)], group_by=[out(0)]), None),
     ]
     for img in (N.testtbl_v2(), os.path.join(T.GOLDEN, "testtbl.cst")):
         t = ctx.open_file(img) if isinstance(img, str) else ctx.open_image(img)
