@@ -650,15 +650,26 @@ __global__ void __launch_bounds__(kBlock) k_flatten_parent(const u8* leaf_levels
   }
 }
 
-// AGGREGATE_WITHIN_RECORD_FLAT: every thread walks 8 consecutive flattened rows,
-// keeps the running per-record sums in registers and adds them to the record's
-// output words when the record changes (rows of one record are adjacent, so a
-// thread issues ~1 atomic per aggregate and record it touches)
+// AGGREGATE_WITHIN_RECORD_FLAT: every thread walks a window of 8 consecutive
+// flattened rows (rows of one record are adjacent).  Records inside one window
+// are summed in registers and stored plainly.  A record that spans windows is
+// owned by the thread holding its level-0 slot: it adds the `head` partial sums
+// (rows before a window's first level-0 slot) of the following threads from LDS
+// and stores the total.  Only the records that cross a 2048-row tile boundary
+// (<= 2 per tile) are added atomically -- measured on MI355X, mixing plain stores
+// and atomics at window granularity cost 5.5 ms per 2.1e8 rows against 1.1 ms for
+// stores only (out[] is zero-filled by the caller).  All arrays are padded by
+// >= 8192 slots (padded_rows): windows and the peek behind the tile are readable.
 __global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
+  __shared__ u64 s_head[kBlock];
+  __shared__ u8 s_hz[kBlock];
+  const u32 tid = threadIdx.x;
   const u64 tile = blockIdx.x;
-  const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
-  u64 packed = 0;
-  u64 idx = s0;  // records started before row s0
+  const u64 s0 = tile * kDecodeTile + (u64) tid * 8;
+  const u64 tile_end = (tile + 1) * kDecodeTile;
+  u64 packed = 0;        // level bytes of the window (no level stream: all 0)
+  u64 idx0 = s0;         // records started before row s0
+  bool tile_closed = true;  // the tile's last record ends with the tile
   if (a.leaf_levels) {
     packed = *reinterpret_cast<const u64*>(a.leaf_levels + s0);
     u32 cnt = 0;
@@ -667,38 +678,84 @@ __global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
       cnt += (((packed >> (8 * j)) & 0xff) == 0 && s0 + j < a.nflat) ? 1 : 0;
     }
     u32 total;
-    idx = a.rec_offsets[tile] + block_excl_scan(cnt, &total);
+    idx0 = a.rec_offsets[tile] + block_excl_scan(cnt, &total);
+    tile_closed = tile_end >= a.nflat || a.leaf_levels[tile_end] == 0;
   }
-  u64 acc[kMaxWithinAggs];
-#pragma unroll
-  for (u32 e = 0; e < kMaxWithinAggs; ++e) acc[e] = 0;
-  auto flush = [&](u64 rec) {
-    if (rec >= a.nrec) return;
-#pragma unroll
-    for (u32 e = 0; e < kMaxWithinAggs; ++e) {
-      if (e < a.n && acc[e]) atomicAdd(reinterpret_cast<unsigned long long*>(a.out[e] + rec),
-                                       (unsigned long long) acc[e]);
-      acc[e] = 0;
-    }
-  };
+  // has_zero: the window holds a level-0 slot; a window behind the last row ends
+  // every chain with an empty head
+  bool hz = s0 >= a.nflat;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const u64 s = s0 + j;
-    if (s < a.nflat) {
-      const u32 lvl = (u32) ((packed >> (8 * j)) & 0xff);
-      if (lvl == 0) {
-        if (j > 0 && idx > 0) flush(idx - 1);
-        ++idx;
-      }
+    hz = hz || (s0 + j < a.nflat && ((packed >> (8 * j)) & 0xff) == 0);
+  }
+  s_hz[tid] = hz ? 1 : 0;
+  for (u32 e = 0; e < a.n; ++e) {
+    const u32 lmax = a.level[e];
+    u64 v[8];
+    if (!a.is_count[e] && a.src[e]) {
+      typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+      const u64x2_t* p = reinterpret_cast<const u64x2_t*>(a.src[e] + s0);
 #pragma unroll
-      for (u32 e = 0; e < kMaxWithinAggs; ++e) {
-        if (e < a.n && a.level[e] >= lvl) {
-          acc[e] += a.is_count[e] ? 1ull : (a.src[e] ? a.src[e][s] : a.lit[e]);
+      for (int j = 0; j < 4; ++j) {
+        const u64x2_t x = __builtin_nontemporal_load(p + j);
+        v[2 * j] = x.x;
+        v[2 * j + 1] = x.y;
+      }
+    } else {
+      const u64 c = a.is_count[e] ? 1ull : a.lit[e];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = c;
+    }
+    u64* out = (u64*) a.out[e];
+    u64 idx = idx0, acc = 0, head = 0;
+    bool started = false;  // a level-0 slot was seen in this window
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (s0 + j < a.nflat) {
+        const u32 lvl = (u32) ((packed >> (8 * j)) & 0xff);
+        if (lvl == 0) {
+          if (!started) {
+            head = acc;
+          } else if (idx - 1 < a.nrec && acc) {
+            out[idx - 1] = acc;  // record inside the window
+          }
+          acc = 0;
+          ++idx;
+          started = true;
+        }
+        if (lmax >= lvl) acc += v[j];
+      }
+    }
+    if (!started) head = acc;
+    s_head[tid] = head;
+    __syncthreads();
+    if (started) {
+      // the record of the window's last level-0 slot: + the heads that follow
+      u64 sum = acc;
+      u32 t = tid + 1;
+      while (t < kBlock && !s_hz[t]) sum += s_head[t++];
+      const bool closed = t < kBlock || tile_closed;
+      if (t < kBlock) sum += s_head[t];
+      if (idx - 1 < a.nrec && sum) {
+        if (closed) {
+          out[idx - 1] = sum;
+        } else {
+          atomicAdd(reinterpret_cast<unsigned long long*>(out + idx - 1), (unsigned long long) sum);
         }
       }
     }
+    if (tid == 0 && idx0 > 0 && s0 < a.nflat && (packed & 0xff) != 0) {
+      // the tile starts inside record idx0 - 1 (it began in an earlier tile)
+      u64 sum = 0;
+      u32 t = 0;
+      while (t < kBlock && !s_hz[t]) sum += s_head[t++];
+      if (t < kBlock) sum += s_head[t];
+      if (idx0 - 1 < a.nrec && sum) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(out + idx0 - 1), (unsigned long long) sum);
+      }
+    }
+    __syncthreads();
   }
-  if (idx > 0) flush(idx - 1);
 }
 
 // tags (0 defined / 1 undefined) of a nested column from decoded level bytes

@@ -231,6 +231,10 @@ evql_table::~evql_table() {
   for (auto& kv : nested_cache) {
     if (kv.second.d_values) hipFree(kv.second.d_values);
   }
+  for (auto& kv : leaf_cache) {
+    if (kv.second.levels) hipFree(kv.second.levels);
+    if (kv.second.rec_offsets) hipFree(kv.second.rec_offsets);
+  }
 }
 
 evql_query::~evql_query() {
@@ -642,12 +646,7 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
   return Status();
 }
 
-// the leaf's decoded repetition levels and the scanned per-tile counts of its
-// level-0 slots (= records started), kept for the WITHIN RECORD reduction
-struct LeafLevels {
-  DevBuf<uint8_t> levels;
-  DevBuf<uint64_t> rec_offsets;
-};
+using LeafLevels = evql_table::LeafLevels;
 
 // flattens `cols` (all of one ancestor chain) to one value per leaf slot:
 // (*flat)[i] is borrowed from the table's nested cache
@@ -679,9 +678,10 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
   const int leaf_li = kp.cols[leaf].layout_index;
   {
     // every column already flattened for this leaf by an earlier operator?
-    bool all = keep == nullptr;
+    bool all = keep == nullptr || lc.rlevel_max == 0 || t->leaf_cache.count(leaf_li);
     for (const auto& c : kp.cols) all = all && t->nested_cache.count({c.layout_index, leaf_li});
     if (all) {
+      if (keep && lc.rlevel_max > 0) *keep = t->leaf_cache[leaf_li];
       for (size_t i = 0; i < kp.cols.size(); ++i) {
         const auto& e = t->nested_cache[{kp.cols[i].layout_index, leaf_li}];
         nested_flat[i] = e.d_values;
@@ -796,9 +796,15 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
     }
   }
   if (keep && lc.rlevel_max > 0) {
-    keep->levels.p = d_leaf_levels.release();
-    keep->rec_offsets.p = thr_offsets[0];  // threshold 0 comes first
-    thr_offsets[0] = nullptr;
+    auto hit = t->leaf_cache.find(leaf_li);
+    if (hit == t->leaf_cache.end()) {
+      LeafLevels ll;
+      ll.levels = d_leaf_levels.release();
+      ll.rec_offsets = thr_offsets[0];  // threshold 0 comes first
+      thr_offsets[0] = nullptr;
+      hit = t->leaf_cache.emplace(leaf_li, ll).first;
+    }
+    *keep = hit->second;
   }
   return Status();
 }
@@ -821,8 +827,8 @@ static Status materialize_within_record(evql_query* q) {
   Status st = materialize_nested(q, q->wr_cols, &flat, &nflat, &leaf);
   if (!st.ok()) return st;
   WithinRecordArgs a{};
-  a.leaf_levels = leaf.levels.p;
-  a.rec_offsets = leaf.rec_offsets.p;
+  a.leaf_levels = leaf.levels;
+  a.rec_offsets = leaf.rec_offsets;
   a.nflat = nflat;
   a.nrec = nrec;
   a.n = uint32_t(q->wr_aggs.size());

@@ -161,6 +161,14 @@ struct evql_table {
     uint64_t nflat = 0;
   };
   std::map<std::pair<int, int>, NestedFlat> nested_cache;
+  // record scans (WITHIN RECORD): the leaf's decoded repetition levels (one byte
+  // per slot) and the scanned per-tile counts of its level-0 slots (= records
+  // started before the tile), keyed by the leaf's layout index
+  struct LeafLevels {
+    uint8_t* levels = nullptr;
+    uint64_t* rec_offsets = nullptr;
+  };
+  std::map<int, LeafLevels> leaf_cache;
   ~evql_table();
 };
 

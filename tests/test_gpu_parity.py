@@ -721,6 +721,51 @@ def test_within_record_scan(ctx):
     t.close()
 
 
+def test_within_record_long_records(ctx):
+    """records of 0 .. 9000 items: spanning many 8-row windows and 2048-row tiles of
+    k_within_record (plain stores inside a tile, atomics across tile borders),
+    against numpy segment sums and the oracle"""
+    from eventql_amd.plan import out
+    rng = np.random.default_rng(11)
+    cnt = rng.choice([0, 1, 2, 7, 8, 9, 40, 300, 2047, 2048, 2049, 5000, 9000], 400)
+    nrec = len(cnt)
+    slots = np.maximum(cnt, 1)
+    total = int(slots.sum())
+    starts = np.concatenate([[0], np.cumsum(slots)[:-1]])
+    rl = np.ones(total, np.uint64)
+    rl[starts] = 0
+    rec_of_slot = np.repeat(np.arange(nrec), slots)
+    dl = np.where(cnt[rec_of_slot] > 0, 2, 0).astype(np.uint64)
+    price = rng.integers(1, 1 << 40, total).astype(np.uint64)
+    w = E.Writer([
+        dict(name="id", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+        dict(name="items.price", logical_type=K.COL_UNSIGNED_INT,
+             storage_type=K.ENC_UINT64_PLAIN, rlevel_max=1, dlevel_max=2)])
+    w.put("id", np.arange(nrec, dtype=np.uint64))
+    w.put("items.price", price, rlvl=rl, dlvl=dl)
+    w.commit(nrec)
+    img = w.image()
+    w.close()
+    t = ctx.open_image(img)
+    S = {"id": K.T_UINT64, "items.price": K.T_UINT64}
+    plan = Plan(S, scan_select=[sum_(col("id")), count(col("items.price")),
+                                sum_(col("items.price")), sum_(lit(3))],
+                select=[out(0), sum_(out(1)), sum_(out(2)), sum_(out(3)), count(1)],
+                group_by=[out(0)], scan_mode=K.SCAN_NESTED_WITHIN_RECORD)
+    got = sorted(t.query(plan).run().rows())
+    defined = dl == 2
+    psum = np.bincount(rec_of_slot, weights=None, minlength=nrec)
+    exp = []
+    for r in range(nrec):
+        seg = slice(starts[r], starts[r] + slots[r])
+        # (a literal has repetition level 0: accumulated on the record's first row only)
+        exp.append((r, int(slots[r]), int(price[seg][defined[seg]].sum(dtype=np.uint64)), 3, 1))
+    assert psum.tolist() == slots.tolist()
+    assert got == exp
+    T.compare_results(got, sorted(O.oracle_run(img, plan).rows()), [K.T_UINT64] * 5, key_cols=1)
+    t.close()
+
+
 def _small_table(ctx, cols, specs, n):
     w = E.Writer(specs)
     for s in specs:
