@@ -218,7 +218,8 @@ def main():
             qq.launch()
             qq.finish()
             n = drain(qq)
-            step.kernel_ms = qq.stats()["kernel_ms"]
+            step.stats = qq.stats()
+            step.kernel_ms = step.stats["kernel_ms"]
             qq.close()
             return n
         q.launch()
@@ -271,7 +272,7 @@ def main():
         if high_card:
             ngroups_out = int(g.item())
 
-    stats = q.stats()
+    stats = getattr(step, "stats", None) or q.stats()
     if rank == 0:
         total_rows = rows * world * args.steps
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
