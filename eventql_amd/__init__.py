@@ -68,6 +68,9 @@ def lib():
     L.evql_table_image_size.argtypes = [C.c_void_p]
     L.evql_table_download_image.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.evql_table_generate.argtypes = [C.c_void_p, C.POINTER(K.SynthSpec), C.POINTER(C.c_void_p)]
+    L.evql_table_from_device_columns.argtypes = [C.c_void_p, C.POINTER(K.ColumnSpec), C.c_int,
+                                                 C.POINTER(K.DeviceColumn), C.c_uint64,
+                                                 C.POINTER(C.c_void_p)]
     L.evql_writer_create.argtypes = [C.POINTER(K.ColumnSpec), C.c_int, C.POINTER(C.c_void_p)]
     L.evql_writer_put_uint.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p, _u64p]
     L.evql_writer_put_float.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p, _f64p]
@@ -248,6 +251,23 @@ class Context:
                            k_bits)
         t = C.c_void_p()
         _check(lib().evql_table_generate(self.h, C.byref(spec), C.byref(t)))
+        return Table(self, t)
+
+    def table_from_device_columns(self, columns, values, nulls, num_rows):
+        """evql_table_from_device_columns: `columns` as for Writer; values[name] /
+        nulls[name] are DEVICE addresses (e.g. torch tensor .data_ptr()) of num_rows
+        u64 value words / NULL-flag bytes (nulls only for optional columns)"""
+        names = [c["name"].encode() for c in columns]
+        specs = (K.ColumnSpec * len(columns))()
+        data = (K.DeviceColumn * len(columns))()
+        for i, c in enumerate(columns):
+            specs[i] = K.ColumnSpec(names[i], c["logical_type"], c["storage_type"],
+                                    c.get("column_id", i + 1), c.get("rlevel_max", 0),
+                                    c.get("dlevel_max", 0), c.get("bitpack_max_value", 0))
+            data[i] = K.DeviceColumn(values[c["name"]], (nulls or {}).get(c["name"]))
+        t = C.c_void_p()
+        _check(lib().evql_table_from_device_columns(self.h, specs, len(columns), data, num_rows,
+                                                    C.byref(t)))
         return Table(self, t)
 
     def close(self):

@@ -134,6 +134,10 @@ class ColumnSpec(C.Structure):
     ]
 
 
+class DeviceColumn(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("nulls", C.c_void_p)]
+
+
 class ColumnBuf(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_size_t)]
 

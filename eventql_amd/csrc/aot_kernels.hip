@@ -968,6 +968,179 @@ hipError_t launch_lsm_filter(const LsmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- device-side cstable writer (io/cstable/page_writer_*.cc) -----------------------
+namespace {
+
+__device__ __forceinline__ u8* wr_stream_byte(u8* image, const u64* pages, u64 pos) {
+  return image + pages[pos >> 19] + (pos & 0x7ffffu);  // 512 KiB pages
+}
+
+// per-tile (2048 rows) counts of the defined rows (nulls[r] == 0)
+__global__ void __launch_bounds__(kBlock) k_wr_count_defined(const u8* nulls, u64 nrows,
+                                                             u64* tile_counts) {
+  const u64 r0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += (r0 + j < nrows && nulls[r0 + j] == 0) ? 1 : 0;
+  u32 total;
+  block_excl_scan(cnt, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+// dense[#defined rows before r] = values[r] for every defined row r
+__global__ void __launch_bounds__(kBlock) k_wr_compact(const u64* values, const u8* nulls,
+                                                       const u64* tile_offsets, u64 nrows,
+                                                       u64* dense) {
+  const u64 r0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += (r0 + j < nrows && nulls[r0 + j] == 0) ? 1 : 0;
+  u32 total;
+  u64 idx = tile_offsets[blockIdx.x] + block_excl_scan(cnt, &total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (r0 + j < nrows && nulls[r0 + j] == 0) dense[idx++] = values[r0 + j];
+  }
+}
+
+// BitPackedIntPageWriter (page_writer_bitpacked.cc:43-100): blocks of 128 values in
+// libsimdcomp's 4-lane layout, 1024 blocks per page, a 4-byte max_value header in
+// front of the first page.  One thread per 32-bit output word: word w of lane l
+// holds bits [32w, 32w + 32) of the lane's stream of 32 `bits`-wide values.
+// dense == NULL: the stream of definition levels, 1 - nulls[i].
+__global__ void __launch_bounds__(kBlock) k_wr_bitpack(u8* image, const u64* pages,
+                                                       const u64* dense, const u8* nulls, u64 n,
+                                                       u32 bits) {
+  const u64 wi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  const u64 nblocks = (n + 127) / 128;
+  if (wi >= nblocks * 4 * bits) return;
+  const u64 blk = wi / (4 * bits);
+  const u32 rem = (u32) (wi % (4 * bits));
+  const u32 w = rem >> 2, lane = rem & 3;
+  const u64 mask = bits >= 32 ? 0xffffffffull : ((1ull << bits) - 1);
+  u32 word = 0;
+  for (u32 k = (32 * w) / bits; k < 32 && k * bits < 32 * w + 32; ++k) {
+    const u64 i = blk * 128 + 4 * k + lane;
+    u64 v = 0;
+    if (i < n) v = dense ? dense[i] : (nulls[i] ? 0ull : 1ull);
+    v &= mask;
+    const int sh = (int) (k * bits) - (int) (32 * w);
+    word |= sh >= 0 ? (u32) (v << sh) : (u32) (v >> (-sh));
+  }
+  const u64 page = blk / 1024, inblk = blk % 1024;
+  u8* dst = image + pages[page] + (page == 0 ? 4 : 0) + inblk * 16 * bits + (u64) rem * 4;
+  *reinterpret_cast<u32*>(dst) = word;
+}
+
+// UInt64PageWriter / UInt32PageWriter: value i at stream byte i * width
+__global__ void __launch_bounds__(kBlock) k_wr_plain(u8* image, const u64* pages,
+                                                     const u64* dense, u64 n, u32 width) {
+  for (u64 i = (u64) blockIdx.x * kBlock + threadIdx.x; i < n; i += (u64) gridDim.x * kBlock) {
+    u8* dst = wr_stream_byte(image, pages, i * width);
+    if (width == 8) {
+      *reinterpret_cast<u64*>(dst) = dense[i];
+    } else {
+      *reinterpret_cast<u32*>(dst) = (u32) dense[i];
+    }
+  }
+}
+
+__device__ __forceinline__ u32 wr_leb_len(u64 v) {
+  const u32 nbits = v ? 64 - (u32) __clzll((long long) v) : 1;
+  return (nbits + 6) / 7;
+}
+
+// LEB128PageWriter (page_writer_leb128.cc): bytes per 2048-value chunk ...
+__global__ void __launch_bounds__(kBlock) k_wr_leb_count(const u64* dense, u64 n,
+                                                         u64* chunk_bytes) {
+  const u64 i0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 len = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) len += i0 + j < n ? wr_leb_len(dense[i0 + j]) : 0;
+  u32 total;
+  block_excl_scan(len, &total);
+  if (threadIdx.x == 0) chunk_bytes[blockIdx.x] = total;
+}
+
+// ... and the bytes themselves at their stream positions (values may straddle pages)
+__global__ void __launch_bounds__(kBlock) k_wr_leb_emit(u8* image, const u64* pages,
+                                                        const u64* dense, u64 n,
+                                                        const u64* chunk_offsets) {
+  const u64 i0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 len = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) len += i0 + j < n ? wr_leb_len(dense[i0 + j]) : 0;
+  u32 total;
+  u64 pos = chunk_offsets[blockIdx.x] + block_excl_scan(len, &total);
+  for (int j = 0; j < 8; ++j) {
+    if (i0 + j >= n) break;
+    u64 v = dense[i0 + j];
+    do {
+      u8 b = v & 0x7f;
+      v >>= 7;
+      if (v) b |= 0x80;
+      *wr_stream_byte(image, pages, pos++) = b;
+    } while (v);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_wr_count_defined(const uint8_t* nulls, uint64_t nrows, uint64_t* tile_counts,
+                                   hipStream_t s) {
+  const u64 ntiles = (nrows + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_count_defined, dim3((unsigned) ntiles), dim3(kBlock), 0, s, nulls,
+                     (u64) nrows, (u64*) tile_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_compact(const uint64_t* values, const uint8_t* nulls,
+                             const uint64_t* tile_offsets, uint64_t nrows, uint64_t* dense,
+                             hipStream_t s) {
+  const u64 ntiles = (nrows + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_compact, dim3((unsigned) ntiles), dim3(kBlock), 0, s,
+                     (const u64*) values, nulls, (const u64*) tile_offsets, (u64) nrows,
+                     (u64*) dense);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_bitpack(uint8_t* image, const uint64_t* pages, const uint64_t* dense,
+                             const uint8_t* nulls, uint64_t n, uint32_t bits, hipStream_t s) {
+  const u64 words = (n + 127) / 128 * 4 * bits;
+  if (words == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_bitpack, dim3((unsigned) ((words + kBlock - 1) / kBlock)), dim3(kBlock),
+                     0, s, image, (const u64*) pages, (const u64*) dense, nulls, (u64) n, bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_plain(uint8_t* image, const uint64_t* pages, const uint64_t* dense,
+                           uint64_t n, uint32_t width, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_plain, dim3(grid_for(n, kBlock, 65536)), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (const u64*) dense, (u64) n, width);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_leb_count(const uint64_t* dense, uint64_t n, uint64_t* chunk_bytes,
+                               hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_leb_count, dim3((unsigned) ntiles), dim3(kBlock), 0, s,
+                     (const u64*) dense, (u64) n, (u64*) chunk_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_leb_emit(uint8_t* image, const uint64_t* pages, const uint64_t* dense,
+                              uint64_t n, const uint64_t* chunk_offsets, hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_leb_emit, dim3((unsigned) ntiles), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (const u64*) dense, (u64) n, (const u64*) chunk_offsets);
+  return hipGetLastError();
+}
+
 hipError_t launch_synth(const SynthArgs* d_args, uint64_t num_rows, hipStream_t s) {
   const u64 nchunks = (num_rows + 127) / 128;
   if (nchunks == 0) return hipSuccess;

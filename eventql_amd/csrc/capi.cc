@@ -364,6 +364,39 @@ int evql_table_generate(evql_ctx_t* ctx, const evql_synth_spec_t* spec, evql_tab
   API_CATCH
 }
 
+// ---- device-side writer -----------------------------------------------------------------
+int evql_table_from_device_columns(evql_ctx_t* ctx, const evql_column_spec_t* cols, int ncols,
+                                   const evql_device_column_t* data, uint64_t num_rows,
+                                   evql_table_t** out) {
+  API_TRY
+  if (!ctx || !cols || !data || !out || ncols <= 0) return fail(EVQL_EARG, "bad arguments");
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
+  std::vector<ColumnSpec> specs;
+  std::vector<DeviceColumnIn> in;
+  for (int i = 0; i < ncols; ++i) {
+    ColumnSpec cs;
+    cs.name = cols[i].name;
+    cs.logical_type = ColumnType(cols[i].logical_type);
+    cs.storage_type = ColumnEncoding(cols[i].storage_type);
+    cs.column_id = cols[i].column_id;
+    cs.rlevel_max = cols[i].rlevel_max;
+    cs.dlevel_max = cols[i].dlevel_max;
+    cs.bitpack_max_value = cols[i].bitpack_max_value;
+    if (cs.bitpack_max_value == 0) {
+      cs.bitpack_max_value =
+          cs.storage_type == ColumnEncoding::BOOLEAN_BITPACKED ? 1u : 0xffffffffu;
+    }
+    specs.push_back(cs);
+    in.push_back({data[i].values, data[i].nulls});
+  }
+  evql_table* t = nullptr;
+  Status st = table_from_device_columns(ctx, specs, in, num_rows, &t);
+  if (!st.ok()) return ret(st);
+  *out = t;
+  return EVQL_OK;
+  API_CATCH
+}
+
 // ---- writer --------------------------------------------------------------------------
 int evql_writer_create(const evql_column_spec_t* cols, int ncols, evql_writer_t** out) {
   API_TRY

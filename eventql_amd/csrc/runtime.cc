@@ -159,7 +159,7 @@ static uint64_t stream_payload_bytes(const std::vector<uint8_t>& img, const Colu
   return total;
 }
 
-static Status upload_page_tables(evql_table* t) {
+Status upload_page_tables(evql_table* t) {
   t->d_pages.assign(t->layout.columns.size(), std::vector<uint64_t*>(3, nullptr));
   for (size_t i = 0; i < t->layout.columns.size(); ++i) {
     const ColumnLayout& c = t->layout.columns[i];

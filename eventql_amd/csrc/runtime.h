@@ -264,4 +264,14 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
 // row-addressable device view of a flat column (direct pages or cached SoA decode)
 Status table_rt_column(evql_table* t, const std::string& name, RtColumn* out,
                        const uint64_t** strpos);
+// device copies of the page offset lists of `t->layout` -> t->d_pages
+Status upload_page_tables(evql_table* t);
+// device_writer.cc: a cstable v0.2.0 image encoded on the device from SoA columns
+struct DeviceColumnIn {
+  const uint64_t* values;  // device, num_rows value words
+  const uint8_t* nulls;    // device, num_rows bytes (1 = NULL) or nullptr
+};
+Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& specs,
+                                 const std::vector<DeviceColumnIn>& in, uint64_t num_rows,
+                                 evql_table** out);
 }  // namespace evql

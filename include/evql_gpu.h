@@ -304,6 +304,35 @@ int evql_writer_write_file(const evql_writer_t* w, const char* path);
 void evql_writer_destroy(evql_writer_t* w);
 
 /* ------------------------------------------------------------------------ */
+/* device-side cstable writer                                                  */
+/*   the write side of compaction / result materialisation:                    */
+/*   cstable::CSTableWriter::commitV2 (io/cstable/cstable_writer.cc:267-294),  */
+/*   UInt64PageWriter / UInt32PageWriter / BitPackedIntPageWriter /            */
+/*   LEB128PageWriter (io/cstable/columns/page_writer_*.cc), file index +      */
+/*   metablock (io/cstable/cstable_file.cc:136-184)                            */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const uint64_t* values; /* DEVICE pointer: num_rows value words (u64 / f64 bits
+                           * / bool as 0|1); entries of NULL rows are ignored */
+  const uint8_t* nulls;   /* DEVICE pointer: num_rows bytes, 1 = NULL; given
+                           * exactly for optional columns (dlevel_max == 1) */
+} evql_device_column_t;
+/*
+ * Encodes `ncols` SoA columns that sit in HBM into a cstable v0.2.0 image, in
+ * HBM, and returns it as a table (evql_table_download_image / _write_file give
+ * the file).  Flat schemas: required or optional (dlevel_max 1) columns in
+ * UINT64_PLAIN, FLOAT_IEEE754, UINT32_PLAIN, UINT32_BITPACKED,
+ * BOOLEAN_BITPACKED or UINT64_LEB128; repeated / nested columns and strings
+ * answer EVQL_ENOTSUP (evql_writer_* covers them on the host).  Pages are placed
+ * column after column (an optional column's definition levels before its data);
+ * for required columns the file is byte-identical to the one evql_writer_*
+ * produces from the same values.
+ */
+int evql_table_from_device_columns(evql_ctx_t* ctx, const evql_column_spec_t* cols,
+                                   int ncols, const evql_device_column_t* data,
+                                   uint64_t num_rows, evql_table_t** out);
+
+/* ------------------------------------------------------------------------ */
 /* the operator: GroupByExpression over FastCSTableScan / CSTableScan         */
 /* ------------------------------------------------------------------------ */
 typedef enum {

@@ -1,0 +1,151 @@
+"""Device-side cstable writer (evql_table_from_device_columns) against the host
+writer (evql_writer_*, itself validated against the reference's reader): the file
+bytes for required columns, the decoded (d, value) streams through the oracle's
+reader for optional ones, and query results over the written table."""
+import numpy as np
+import pytest
+import torch
+
+import eventql_amd as E
+from eventql_amd import capi as K
+from eventql_amd.plan import Plan, col, count, sum_, min_, max_
+import oracle_lib as O
+import tables as T
+
+pytestmark = pytest.mark.gpu
+
+U, F, B = K.COL_UNSIGNED_INT, K.COL_FLOAT, K.COL_BOOLEAN
+REQUIRED = [
+    dict(name="p64", logical_type=U, storage_type=K.ENC_UINT64_PLAIN),
+    dict(name="f", logical_type=F, storage_type=K.ENC_FLOAT_IEEE754),
+    dict(name="p32", logical_type=U, storage_type=K.ENC_UINT32_PLAIN),
+    dict(name="bp10", logical_type=U, storage_type=K.ENC_UINT32_BITPACKED, bitpack_max_value=1023),
+    dict(name="bp32", logical_type=U, storage_type=K.ENC_UINT32_BITPACKED),
+    dict(name="bp17", logical_type=U, storage_type=K.ENC_UINT32_BITPACKED,
+         bitpack_max_value=(1 << 17) - 1),
+    dict(name="flag", logical_type=B, storage_type=K.ENC_BOOLEAN_BITPACKED),
+    dict(name="leb", logical_type=U, storage_type=K.ENC_UINT64_LEB128),
+]
+OPTIONAL = [dict(c, name="o_" + c["name"], dlevel_max=1) for c in REQUIRED]
+
+
+def make_columns(n, seed):
+    rng = np.random.default_rng(seed)
+    c = {
+        "p64": rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1),
+        "f": rng.normal(0, 1e6, n).view(np.uint64),
+        "p32": rng.integers(0, 1 << 32, n, dtype=np.uint64),
+        "bp10": rng.integers(0, 1024, n, dtype=np.uint64),
+        "bp32": rng.integers(0, 1 << 32, n, dtype=np.uint64),
+        "bp17": rng.integers(0, 1 << 17, n, dtype=np.uint64),
+        "flag": rng.integers(0, 2, n, dtype=np.uint64),
+        # every LEB128 length, 1 .. 10 bytes
+        "leb": (rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) >>
+               rng.integers(0, 64, n).astype(np.uint64),
+    }
+    for name in list(c):
+        c["o_" + name] = c[name].copy()
+        c["o_" + name + "_null"] = (rng.random(n) < 0.3).astype(np.uint8)
+    return c
+
+
+def host_image(specs, c, n):
+    w = E.Writer(specs)
+    for s in specs:
+        name = s["name"]
+        v = c[name].view(np.float64) if s["logical_type"] == F else c[name]
+        pres = None
+        if s.get("dlevel_max", 0):
+            pres = (1 - c[name + "_null"]).astype(np.uint8)
+        w.put(name, v, present=pres)
+    w.commit(n)
+    img = w.image()
+    w.close()
+    return img
+
+
+def device_table(ctx, specs, c, n):
+    keep, vals, nulls = [], {}, {}
+    for s in specs:
+        name = s["name"]
+        tv = torch.from_numpy(c[name].view(np.int64).copy()).cuda()
+        keep.append(tv)
+        vals[name] = tv.data_ptr() if n else None
+        if s.get("dlevel_max", 0):
+            tn = torch.from_numpy(c[name + "_null"].copy()).cuda()
+            keep.append(tn)
+            # (an empty tensor has no storage: any non-null address will do for n == 0)
+            nulls[name] = tn.data_ptr() if n else 1
+    torch.cuda.synchronize()
+    t = ctx.table_from_device_columns(specs, vals, nulls, n)
+    del keep
+    return t
+
+
+@pytest.mark.parametrize("n", [0, 1, 127, 128, 129, 2049, 65536, 65537, 131072, 131073, 400_001])
+def test_required_columns_are_byte_identical_to_the_host_writer(ctx, n):
+    c = make_columns(n, 100 + n)
+    t = device_table(ctx, REQUIRED, c, n)
+    assert t.num_rows == n
+    dev = t.download_image()
+    t.close()
+    host = host_image(REQUIRED, c, n)
+    assert len(dev) == len(host)
+    assert dev == host
+
+
+@pytest.mark.parametrize("n", [0, 1, 129, 5000, 131073, 700_001])
+def test_optional_columns_round_trip(ctx, n, tmp_path):
+    c = make_columns(n, 200 + n)
+    specs = OPTIONAL + REQUIRED[:1]
+    t = device_table(ctx, specs, c, n)
+    dev = t.download_image()
+    host = host_image(specs, c, n)
+    if n <= 5000:
+        # every stream fits one page: same page order as the host writer
+        assert dev == host
+    path = str(tmp_path / "dev.cst")
+    with open(path, "wb") as f:
+        f.write(dev)
+    for kind in (("orc", "ref") if O.have_ref() else ("orc",)):
+        r = O.TableReader(path, kind)
+        assert {x["name"] for x in r.columns()} == {s["name"] for s in specs}
+        for s in OPTIONAL:
+            name = s["name"]
+            is_float = s["logical_type"] == F
+            rl, dl, pr, v = r.read(name, n, "float" if is_float else "uint")
+            null = c[name + "_null"].astype(bool)
+            assert (np.asarray(dl) == (1 - c[name + "_null"])).all()
+            exp = c[name].copy()
+            got = (np.asarray(v, np.float64).view(np.uint64) if is_float
+                   else np.asarray(v, np.uint64))
+            assert (got[~null] == exp[~null]).all(), name
+        r.close()
+    # and the operator reads the device-written table like the host-written one
+    if n:
+        S = {"o_bp10": K.T_UINT64, "o_p64": K.T_UINT64, "o_leb": K.T_UINT64, "o_f": K.T_FLOAT64,
+             "p64": K.T_UINT64}
+        plan = Plan(S, select=[col("o_bp10"), count(1), sum_(col("o_leb")), min_(col("o_f")),
+                               max_(col("o_p64")), sum_(col("p64"))], group_by=[col("o_bp10")])
+        exp = O.oracle_run(host, plan)
+        q = t.query(plan)
+        T.compare_results(q.run().rows(), exp.rows(), exp.types, key_cols=1)
+        q.close()
+    t.close()
+
+
+def test_not_lowerable_schemas(ctx):
+    x = torch.zeros(16, dtype=torch.int64, device="cuda")
+    for spec in (dict(name="s", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN),
+                 dict(name="r", logical_type=U, storage_type=K.ENC_UINT64_PLAIN, rlevel_max=1,
+                      dlevel_max=1)):
+        with pytest.raises(E.EvqlError) as ei:
+            ctx.table_from_device_columns([spec], {spec["name"]: x.data_ptr()},
+                                          {spec["name"]: x.data_ptr()} if spec.get("dlevel_max")
+                                          else {}, 16)
+        assert ei.value.code == K.EVQL_ENOTSUP
+    # NULL flags without an optional column (and the other way round)
+    spec = dict(name="a", logical_type=U, storage_type=K.ENC_UINT64_PLAIN)
+    with pytest.raises(E.EvqlError) as ei:
+        ctx.table_from_device_columns([spec], {"a": x.data_ptr()}, {"a": x.data_ptr()}, 16)
+    assert ei.value.code == K.EVQL_EARG
