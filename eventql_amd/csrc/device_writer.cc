@@ -216,7 +216,16 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
   // ---- pass 2: the streams, encoded in place ---------------------------------------------------
   const size_t slack = 1 << 20;  // zero slack behind the image (speculative vector loads)
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_image), total + slack));
-  HIP_TRY(hipMemsetAsync(t->d_image, 0, total + slack, s));
+  // every page but a stream's last one is overwritten completely by its encoder:
+  // zero only the last pages (PageManager pages start zero-filled), the index
+  // and the slack
+  for (const auto& cl : t->layout.columns) {
+    for (const std::vector<PageRef>* list : {&cl.dlevel_pages, &cl.data_pages}) {
+      if (list->empty()) continue;
+      HIP_TRY(hipMemsetAsync(t->d_image + list->back().offset, 0, list->back().size, s));
+    }
+  }
+  HIP_TRY(hipMemsetAsync(t->d_image + index_offset, 0, total - index_offset + slack, s));
   HIP_TRY(hipMemcpyAsync(t->d_image, head.data(), head.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(t->d_image + index_offset, idx.data(), idx.size(), hipMemcpyHostToDevice,
                          s));

@@ -53,7 +53,7 @@ def main():
             t = ctx.table_from_device_columns(specs, v, m, n)
             ctx.synchronize()
             dt = time.perf_counter() - t0
-            size = t.image_size
+            size = int(E.lib().evql_table_image_size(t.h))
             t.close()
             best = dt if best is None else min(best, dt)
         in_bytes = n * (8 * len(vals) + len(nl))
