@@ -975,13 +975,28 @@ __device__ __forceinline__ u8* wr_stream_byte(u8* image, const u64* pages, u64 p
   return image + pages[pos >> 19] + (pos & 0x7ffffu);  // 512 KiB pages
 }
 
+// the NULL flags of rows r0 .. r0 + 7, one per byte (rows behind the table: NULL);
+// one 8-byte load where the caller's array allows it
+__device__ __forceinline__ u64 wr_null_bytes(const u8* nulls, u64 r0, u64 nrows) {
+  if (r0 + 8 <= nrows && (reinterpret_cast<uintptr_t>(nulls) & 7) == 0) {
+    return *reinterpret_cast<const u64*>(nulls + r0);
+  }
+  u64 p = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    p |= (u64) ((r0 + j < nrows && nulls[r0 + j] == 0) ? 0 : 1) << (8 * j);
+  }
+  return p;
+}
+
 // per-tile (2048 rows) counts of the defined rows (nulls[r] == 0)
 __global__ void __launch_bounds__(kBlock) k_wr_count_defined(const u8* nulls, u64 nrows,
                                                              u64* tile_counts) {
   const u64 r0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 nb = wr_null_bytes(nulls, r0, nrows);
   u32 cnt = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) cnt += (r0 + j < nrows && nulls[r0 + j] == 0) ? 1 : 0;
+  for (int j = 0; j < 8; ++j) cnt += ((nb >> (8 * j)) & 0xff) == 0 ? 1 : 0;
   u32 total;
   block_excl_scan(cnt, &total);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
@@ -992,14 +1007,29 @@ __global__ void __launch_bounds__(kBlock) k_wr_compact(const u64* values, const 
                                                        const u64* tile_offsets, u64 nrows,
                                                        u64* dense) {
   const u64 r0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 nb = wr_null_bytes(nulls, r0, nrows);
   u32 cnt = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) cnt += (r0 + j < nrows && nulls[r0 + j] == 0) ? 1 : 0;
+  for (int j = 0; j < 8; ++j) cnt += ((nb >> (8 * j)) & 0xff) == 0 ? 1 : 0;
   u32 total;
   u64 idx = tile_offsets[blockIdx.x] + block_excl_scan(cnt, &total);
+  u64 v[8];
+  if (r0 + 8 <= nrows && (reinterpret_cast<uintptr_t>(values) & 15) == 0) {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    const u64x2_t* p = reinterpret_cast<const u64x2_t*>(values + r0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u64x2_t x = p[j];
+      v[2 * j] = x.x;
+      v[2 * j + 1] = x.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = r0 + j < nrows ? values[r0 + j] : 0;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (r0 + j < nrows && nulls[r0 + j] == 0) dense[idx++] = values[r0 + j];
+    if (((nb >> (8 * j)) & 0xff) == 0) dense[idx++] = v[j];
   }
 }
 
@@ -1070,8 +1100,17 @@ __global__ void __launch_bounds__(kBlock) k_wr_leb_emit(u8* image, const u64* pa
   u32 len = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) len += i0 + j < n ? wr_leb_len(dense[i0 + j]) : 0;
+  // the chunk's bytes are contiguous in the stream: staged in LDS (shifted by the
+  // chunk's misalignment so that LDS words and stream words coincide), then
+  // stored as whole 32-bit words -- 4-aligned stream positions never straddle a
+  // page (page size and page offsets are multiples of 4); only the partial words
+  // at the chunk's ends go out bytewise (the neighbour chunk owns their other bytes)
+  __shared__ u32 s_bytes[(kDecodeTile * 10 + 8) / 4];
+  u8* lds = reinterpret_cast<u8*>(s_bytes);
   u32 total;
-  u64 pos = chunk_offsets[blockIdx.x] + block_excl_scan(len, &total);
+  const u64 chunk_off = chunk_offsets[blockIdx.x];
+  const u32 lead = (u32) (chunk_off & 3);
+  u32 lp = lead + block_excl_scan(len, &total);
   for (int j = 0; j < 8; ++j) {
     if (i0 + j >= n) break;
     u64 v = dense[i0 + j];
@@ -1079,8 +1118,21 @@ __global__ void __launch_bounds__(kBlock) k_wr_leb_emit(u8* image, const u64* pa
       u8 b = v & 0x7f;
       v >>= 7;
       if (v) b |= 0x80;
-      *wr_stream_byte(image, pages, pos++) = b;
+      lds[lp++] = b;
     } while (v);
+  }
+  __syncthreads();
+  const u64 a0 = chunk_off - lead;             // aligned stream position of LDS byte 0
+  const u32 end = lead + total;                // LDS bytes [lead, end) are valid
+  for (u32 w = threadIdx.x; w * 4 < end; w += kBlock) {
+    const u32 b0 = w * 4;
+    if (b0 >= lead && b0 + 4 <= end) {
+      *reinterpret_cast<u32*>(wr_stream_byte(image, pages, a0 + b0)) = s_bytes[w];
+    } else {
+      for (u32 b = b0 < lead ? lead : b0; b < b0 + 4 && b < end; ++b) {
+        *wr_stream_byte(image, pages, a0 + b) = lds[b];
+      }
+    }
   }
 }
 

@@ -134,6 +134,22 @@ def test_optional_columns_round_trip(ctx, n, tmp_path):
     t.close()
 
 
+def test_unaligned_input_arrays(ctx):
+    """value / NULL-flag arrays at odd addresses take the scalar load paths"""
+    n = 70_001
+    c = make_columns(n + 1, 7)
+    specs = [OPTIONAL[0], OPTIONAL[7], REQUIRED[7]]
+    tv = {s["name"]: torch.from_numpy(c[s["name"]].view(np.int64).copy()).cuda() for s in specs}
+    tn = {s["name"]: torch.from_numpy(c[s["name"] + "_null"].copy()).cuda() for s in specs[:2]}
+    torch.cuda.synchronize()
+    t = ctx.table_from_device_columns(specs, {k: v[1:].data_ptr() for k, v in tv.items()},
+                                      {k: v[1:].data_ptr() for k, v in tn.items()}, n)
+    dev = t.download_image()
+    t.close()
+    cs = {k: v[1:] for k, v in c.items()}
+    assert dev == host_image(specs, cs, n)
+
+
 def test_not_lowerable_schemas(ctx):
     x = torch.zeros(16, dtype=torch.int64, device="cuda")
     for spec in (dict(name="s", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN),
