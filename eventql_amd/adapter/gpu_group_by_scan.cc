@@ -1,0 +1,265 @@
+/* gpu_group_by_scan.cc -- see gpu_group_by_scan.h */
+#include "gpu_group_by_scan.h"
+#include <string.h>
+#include <eventql/sql/qtree/GroupByNode.h>
+#include <eventql/sql/qtree/SequentialScanNode.h>
+#include <eventql/sql/runtime/QueryBuilder.h>
+#include <eventql/sql/runtime/ValueExpression.h>
+#include <eventql/util/exception.h>
+
+namespace evql_adapter {
+
+const char* statusCodeString(int rc) {
+  switch (rc) {
+    case EVQL_EIO: return "EIO";
+    case EVQL_EARG: return "EARG";
+    default: return "ERUNTIME"; /* util/return_code.h:32-80 knows no other codes */
+  }
+}
+
+/* ---------------------------------------------------------------- registry */
+GpuTableRegistry::GpuTableRegistry(int device_ordinal)
+    : device_(device_ordinal), ctx_(nullptr), ctx_failed_(false) {}
+
+GpuTableRegistry::~GpuTableRegistry() {
+  for (auto& t : tables_) {
+    if (t.second.table) evql_table_close(t.second.table);
+  }
+  if (ctx_) evql_ctx_destroy(ctx_);
+}
+
+void GpuTableRegistry::registerTable(const std::string& table_name,
+                                     const std::string& cstable_file, ScanKind kind) {
+  std::unique_lock<std::mutex> lk(mutex_);
+  auto it = tables_.find(table_name);
+  if (it != tables_.end() && it->second.table) evql_table_close(it->second.table);
+  tables_[table_name] = Entry{cstable_file, kind, nullptr};
+}
+
+evql_ctx_t* GpuTableRegistry::context() {
+  std::unique_lock<std::mutex> lk(mutex_);
+  if (!ctx_ && !ctx_failed_) {
+    if (evql_ctx_create(device_, nullptr, &ctx_) != EVQL_OK) {
+      ctx_failed_ = true; /* no MI355X: every query keeps the CPU operators */
+      ctx_ = nullptr;
+      last_error_ = evql_last_error();
+    }
+  }
+  return ctx_;
+}
+
+evql_table_t* GpuTableRegistry::lookup(const std::string& table_name, ScanKind* kind) {
+  evql_ctx_t* ctx = context();
+  if (!ctx) return nullptr;
+  std::unique_lock<std::mutex> lk(mutex_);
+  auto it = tables_.find(table_name);
+  if (it == tables_.end()) {
+    last_error_ = "table not registered with the GPU executor: " + table_name;
+    return nullptr;
+  }
+  if (!it->second.table) {
+    if (evql_table_open_file(ctx, it->second.file.c_str(), &it->second.table) != EVQL_OK) {
+      last_error_ = evql_last_error();
+      it->second.table = nullptr;
+      return nullptr;
+    }
+  }
+  if (kind) *kind = it->second.kind;
+  return it->second.table;
+}
+
+/* ------------------------------------------------------------ plan lowering */
+static bool lowerExpression(csql::Transaction* txn, RefPtr<csql::ValueExpressionNode> expr,
+                            std::unique_ptr<LoweredProgram>* out, std::string* why) {
+  /* the same call the reference's operators make (scheduler.cc:161-170,
+   * CSTableScan.cc:727-735): qtree -> vm::Program through the runtime's compiler */
+  csql::ValueExpression compiled = txn->getCompiler()->buildValueExpression(txn, expr);
+  out->reset(new LoweredProgram());
+  return lowerProgram(compiled.program(), out->get(), why);
+}
+
+bool buildPlanDesc(csql::Transaction* txn, csql::GroupByNode* group,
+                   csql::SequentialScanNode* seqscan, ScanKind kind, bool partial,
+                   PlanBuffers* pb, std::string* why) {
+  memset(&pb->desc, 0, sizeof(pb->desc));
+
+  /* X_INPUT space of WHERE and the scan select list: selectedColumns() ==
+   * input_columns_ (qtree/SequentialScanNode.cc:151-159), the order in which
+   * FastCSTableScan::execute opens its column readers (CSTableScan.cc:743-752) */
+  pb->scan_column_names = seqscan->selectedColumns();
+  for (size_t i = 0; i < pb->scan_column_names.size(); ++i) {
+    pb->scan_column_ptrs.push_back(pb->scan_column_names[i].c_str());
+    pb->scan_column_types.push_back((uint32_t) seqscan->getInputColumnType(i));
+  }
+
+  auto where = seqscan->whereExpression();
+  if (!where.isEmpty()) {
+    if (!lowerExpression(txn, where.get(), &pb->where, why)) return false;
+  }
+  for (const auto& sl : seqscan->selectList()) {
+    pb->scan_select.emplace_back();
+    if (!lowerExpression(txn, sl->expression(), &pb->scan_select.back(), why)) return false;
+    pb->scan_select_c.push_back(pb->scan_select.back()->c);
+  }
+  if (group) {
+    /* X_INPUT(j) of these programs indexes the scan's select list
+     * (scheduler.cc:153-182: compiled exactly like this) */
+    for (const auto& e : group->groupExpressions()) {
+      pb->group.emplace_back();
+      if (!lowerExpression(txn, e, &pb->group.back(), why)) return false;
+      pb->group_c.push_back(pb->group.back()->c);
+    }
+    for (const auto& sl : group->selectList()) {
+      pb->select.emplace_back();
+      if (!lowerExpression(txn, sl->expression(), &pb->select.back(), why)) return false;
+      pb->select_c.push_back(pb->select.back()->c);
+    }
+  }
+
+  evql_plan_desc_t& d = pb->desc;
+  d.scan_columns = pb->scan_column_ptrs.data();
+  d.scan_column_types = pb->scan_column_types.data();
+  d.n_scan_columns = (uint32_t) pb->scan_column_ptrs.size();
+  d.where = pb->where ? &pb->where->c : nullptr;
+  d.scan_select = pb->scan_select_c.data();
+  d.n_scan_select = (uint32_t) pb->scan_select_c.size();
+  d.group_exprs = pb->group_c.data();
+  d.n_group = (uint32_t) pb->group_c.size();
+  d.select_exprs = pb->select_c.data();
+  d.n_select = (uint32_t) pb->select_c.size();
+  d.group_mode = partial ? EVQL_MODE_PARTIAL : EVQL_MODE_FINAL;
+
+  /* which reference scan operator is being replaced */
+  if (kind == ScanKind::FAST) {
+    d.scan_mode = EVQL_SCAN_FLAT;
+  } else {
+    switch (seqscan->aggregationStrategy()) {
+      case csql::AggregationStrategy::NO_AGGREGATION:
+        d.scan_mode = EVQL_SCAN_NESTED;
+        break;
+      case csql::AggregationStrategy::AGGREGATE_WITHIN_RECORD_FLAT:
+        d.scan_mode = EVQL_SCAN_NESTED_WITHIN_RECORD;
+        break;
+      default:
+        if (why) *why = "aggregation strategy not lowered";
+        return false;
+    }
+  }
+  return true;
+}
+
+/* ----------------------------------------------------------------- operator */
+GpuGroupByScan::GpuGroupByScan(csql::Transaction* txn,
+                               csql::ExecutionContext* execution_context, evql_query_t* query)
+    : txn_(txn), execution_context_(execution_context), query_(query), completed_(false) {
+  execution_context_->incrementNumTasks(); /* groupby.cc:54 */
+}
+
+GpuGroupByScan::~GpuGroupByScan() { evql_query_destroy(query_); }
+
+int GpuGroupByScan::heartbeat(void* self) {
+  auto op = static_cast<GpuGroupByScan*>(self);
+  return op->txn_->triggerHeartbeat().isSuccess() ? 0 : 1; /* groupby.cc:100-105 */
+}
+
+ReturnCode GpuGroupByScan::execute() {
+  execution_context_->incrementNumTasksRunning(); /* groupby.cc:70 */
+  int rc = evql_query_execute(query_, &GpuGroupByScan::heartbeat, this);
+  if (rc != EVQL_OK) {
+    return ReturnCode::error(statusCodeString(rc), evql_last_error());
+  }
+  return ReturnCode::success();
+}
+
+ReturnCode GpuGroupByScan::nextBatch(csql::SVector* columns, size_t* len) {
+  size_t ncols = getColumnCount();
+  std::vector<evql_column_buf_t> bufs(ncols);
+  int rc = evql_query_next_batch(query_, kOutputBatchSize, bufs.data(), len);
+  if (rc != EVQL_OK) {
+    return ReturnCode::error(statusCodeString(rc), evql_last_error());
+  }
+  for (size_t i = 0; i < ncols; ++i) {
+    /* the library hands out packed SVector elements (svalue.cc:410-517) */
+    if (bufs[i].size > 0) columns[i].append(bufs[i].data, bufs[i].size);
+  }
+  if (*len == 0 && !completed_) {
+    completed_ = true;
+    execution_context_->incrementNumTasksCompleted(); /* groupby.cc:211 */
+  }
+  return ReturnCode::success();
+}
+
+size_t GpuGroupByScan::getColumnCount() const {
+  return (size_t) evql_query_column_count(query_);
+}
+
+csql::SType GpuGroupByScan::getColumnType(size_t idx) const {
+  return (csql::SType) evql_query_column_type(query_, (int) idx);
+}
+
+/* ---------------------------------------------------------------- scheduler */
+GpuScheduler::GpuScheduler(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts)
+    : tables_(tables), opts_(opts) {}
+
+csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
+                                              csql::ExecutionContext* execution_context,
+                                              csql::GroupByNode* group,
+                                              csql::SequentialScanNode* seqscan,
+                                              std::string* why) {
+  ScanKind kind = ScanKind::FAST;
+  evql_table_t* table = tables_->lookup(seqscan->tableName(), &kind);
+  if (!table) {
+    *why = tables_->lastError();
+    return nullptr;
+  }
+  PlanBuffers pb;
+  if (!buildPlanDesc(txn, group, seqscan, kind, opts_.partial && group != nullptr, &pb, why)) {
+    return nullptr;
+  }
+  evql_query_t* q = nullptr;
+  int rc = evql_query_create(tables_->context(), table, &pb.desc, &q);
+  if (rc == EVQL_ENOTSUP) {
+    *why = std::string("ENOTSUP: ") + evql_last_error();
+    return nullptr;
+  }
+  if (rc != EVQL_OK) {
+    /* a malformed plan is an error in the reference too (e.g. EARG illegal
+     * column type, CSTableScan.cc:783-784) */
+    RAISE(kRuntimeError, evql_last_error());
+  }
+  return new GpuGroupByScan(txn, execution_context, q);
+}
+
+ScopedPtr<csql::TableExpression> GpuScheduler::buildGroupByExpression(
+    csql::Transaction* txn, csql::ExecutionContext* execution_context,
+    RefPtr<csql::GroupByNode> node) {
+  if (opts_.lower_group_by) {
+    std::string why;
+    csql::TableExpression* op = nullptr;
+    auto seqscan = dynamic_cast<csql::SequentialScanNode*>(node->inputTable().get());
+    if (seqscan) {
+      op = tryLower(txn, execution_context, node.get(), seqscan, &why);
+    } else {
+      why = "input of the GROUP BY is not a sequential scan";
+    }
+    decisions_.push_back(Decision{"groupby", op != nullptr, why});
+    if (op) return ScopedPtr<csql::TableExpression>(op);
+    if (opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
+  }
+  return csql::DefaultScheduler::buildGroupByExpression(txn, execution_context, node);
+}
+
+ScopedPtr<csql::TableExpression> GpuScheduler::buildSequentialScan(
+    csql::Transaction* txn, csql::ExecutionContext* execution_context,
+    RefPtr<csql::SequentialScanNode> node) {
+  if (opts_.lower_scans) {
+    std::string why;
+    csql::TableExpression* op = tryLower(txn, execution_context, nullptr, node.get(), &why);
+    decisions_.push_back(Decision{"seqscan", op != nullptr, why});
+    if (op) return ScopedPtr<csql::TableExpression>(op);
+    if (opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
+  }
+  return csql::DefaultScheduler::buildSequentialScan(txn, execution_context, node);
+}
+
+}  // namespace evql_adapter

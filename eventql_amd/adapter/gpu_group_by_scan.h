@@ -1,0 +1,157 @@
+/*
+ * gpu_group_by_scan.h -- the fused MI355X operator behind the reference's own
+ * operator interface, and the scheduler hook that builds it.
+ *
+ * REFERENCE-SIDE ADAPTER (see gpu_bridge.h): includes reference headers, compiled
+ * only inside a reference build.  In the reference tree this would live next to
+ * sql/statements/select/groupby.h; it is installed exactly like
+ * eventql::Scheduler (server/sql/scheduler.cc:55-77):
+ *
+ *     runtime->setScheduler(mkScoped(new evql_adapter::GpuScheduler(opts)));
+ *
+ *   csql::TableExpression               sql/table_expression.h:35-50
+ *   csql::DefaultScheduler              sql/scheduler.h:78-173 (virtual build*)
+ *   GroupByExpression (replaced)        sql/statements/select/groupby.cc:40-229
+ *   PartialGroupByExpression (replaced) sql/statements/select/groupby.cc:231-491
+ *   FastCSTableScan / CSTableScan (replaced) sql/CSTableScan.cc:187-541, 688-1009
+ */
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <eventql/sql/scheduler.h>
+#include <eventql/sql/table_expression.h>
+#include <eventql/sql/transaction.h>
+#include "evql_gpu.h"
+#include "gpu_bridge.h"
+
+namespace evql_adapter {
+
+/* which reference scan operator the table's provider would have built */
+enum class ScanKind {
+  FAST,   /* FastCSTableScan (CSTableScanProvider.cc:38-54, partition_cursor.cc:199) */
+  DREMEL  /* CSTableScan     (partition_cursor.cc:206-213)                          */
+};
+
+/*
+ * cstable files resident in HBM, keyed by SQL table name.  The reference's
+ * TableProvider hides the file name (CSTableScanProvider::cstable_file_ is
+ * protected), so whoever registers the provider registers the file here too; in
+ * evqld the equivalent call sits in PartitionCursor::openNextTable
+ * (server/sql/partition_cursor.cc:197-213), where the file name is at hand.
+ */
+class GpuTableRegistry {
+public:
+  explicit GpuTableRegistry(int device_ordinal = 0);
+  ~GpuTableRegistry();
+  GpuTableRegistry(const GpuTableRegistry&) = delete;
+
+  void registerTable(const std::string& table_name, const std::string& cstable_file,
+                     ScanKind kind = ScanKind::FAST);
+
+  /* opens (once) and returns the resident table; nullptr when the name is unknown
+   * or no device is present -- the caller then keeps the CPU operators */
+  evql_table_t* lookup(const std::string& table_name, ScanKind* kind);
+  evql_ctx_t* context();
+  const std::string& lastError() const { return last_error_; }
+
+private:
+  struct Entry {
+    std::string file;
+    ScanKind kind;
+    evql_table_t* table;
+  };
+  std::mutex mutex_;
+  int device_;
+  evql_ctx_t* ctx_;
+  bool ctx_failed_;
+  std::map<std::string, Entry> tables_;
+  std::string last_error_;
+};
+
+/* everything evql_query_create reads; owns the lowered programs */
+struct PlanBuffers {
+  std::vector<std::string> scan_column_names;
+  std::vector<const char*> scan_column_ptrs;
+  std::vector<uint32_t> scan_column_types;
+  std::unique_ptr<LoweredProgram> where;
+  std::vector<std::unique_ptr<LoweredProgram>> scan_select, group, select;
+  std::vector<evql_program_t> scan_select_c, group_c, select_c;
+  evql_plan_desc_t desc;
+};
+
+/* Fills `out` from the same objects the reference compiles its operators from
+ * (scheduler.cc:153-182, CSTableScan.cc:726-755).  group == nullptr: a bare scan.
+ * false => not lowerable (*why says what) */
+bool buildPlanDesc(csql::Transaction* txn, csql::GroupByNode* group,
+                   csql::SequentialScanNode* seqscan, ScanKind kind, bool partial,
+                   PlanBuffers* out, std::string* why);
+
+class GpuGroupByScan : public csql::TableExpression {
+public:
+  static const size_t kOutputBatchSize = 1024; /* groupby.h:36, CSTableScan.h:46 */
+
+  GpuGroupByScan(csql::Transaction* txn, csql::ExecutionContext* execution_context,
+                 evql_query_t* query);
+  ~GpuGroupByScan() override;
+
+  ReturnCode execute() override;
+  ReturnCode nextBatch(csql::SVector* columns, size_t* len) override;
+  size_t getColumnCount() const override;
+  csql::SType getColumnType(size_t idx) const override;
+
+private:
+  static int heartbeat(void* self);
+  csql::Transaction* txn_;
+  csql::ExecutionContext* execution_context_;
+  evql_query_t* query_;
+  bool completed_;
+};
+
+struct GpuSchedulerOptions {
+  GpuSchedulerOptions() : lower_group_by(true), lower_scans(false), partial(false),
+                          strict(false) {}
+  bool lower_group_by; /* GroupByExpression + scan -> one fused operator */
+  bool lower_scans;    /* bare FastCSTableScan / CSTableScan -> GPU scan operator */
+  bool partial;        /* build PartialGroupByExpression's twin (a data node) */
+  bool strict;         /* tests: RAISE instead of falling back to the CPU operators */
+};
+
+class GpuScheduler : public csql::DefaultScheduler {
+public:
+  GpuScheduler(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts);
+
+  /* diagnostics: how the last build* calls were answered */
+  struct Decision {
+    std::string node;     /* "groupby" | "seqscan" */
+    bool lowered;
+    std::string reason;   /* why not, when !lowered */
+  };
+  const std::vector<Decision>& decisions() const { return decisions_; }
+  void clearDecisions() { decisions_.clear(); }
+
+protected:
+  ScopedPtr<csql::TableExpression> buildGroupByExpression(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::GroupByNode> node) override;
+
+  ScopedPtr<csql::TableExpression> buildSequentialScan(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::SequentialScanNode> node) override;
+
+  /* nullptr => keep the CPU operators */
+  csql::TableExpression* tryLower(csql::Transaction* txn,
+                                  csql::ExecutionContext* execution_context,
+                                  csql::GroupByNode* group, csql::SequentialScanNode* seqscan,
+                                  std::string* why);
+
+  std::shared_ptr<GpuTableRegistry> tables_;
+  GpuSchedulerOptions opts_;
+  std::vector<Decision> decisions_;
+};
+
+const char* statusCodeString(int evql_status_code);
+
+}  // namespace evql_adapter
