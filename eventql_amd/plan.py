@@ -498,3 +498,86 @@ def unpack_svector(stype, data):
     elif stype == K.T_NIL:
         out = [None] * n
     return out
+
+
+# ---------------------------------------------------------------------------
+# plans from dumped bytecode
+# ---------------------------------------------------------------------------
+class RawProgram:
+    """one evql_program_t from a dump {"code": [[op, argt, arg0, ...]], "static": hex,
+    "method_call", "method_accumulate", "return_type", "aggregate_fn"} -- the form in
+    which the reference-side adapter (eventql_amd/adapter/gpu_bridge.cc) lowers a
+    real csql::vm::Program"""
+
+    def __init__(self, d):
+        code = d["code"]
+        self.code = (K.Instr * max(1, len(code)))(*[K.Instr(c[0], c[1], c[2]) for c in code])
+        st = bytes.fromhex(d["static"]) if d.get("static") else b""
+        buf = st if st else b"\x00"
+        self.static = (C.c_uint8 * len(buf)).from_buffer_copy(buf)
+        self.struct = K.Program(
+            C.cast(self.code, C.POINTER(K.Instr)), len(code), d["method_call"],
+            d["method_accumulate"], d["return_type"], d["aggregate_fn"],
+            C.cast(self.static, C.POINTER(C.c_uint8)), len(st))
+        self.return_type = d["return_type"]
+        self.is_aggregate = d["method_accumulate"] > 0
+
+    @staticmethod
+    def dump_of(compiled):
+        """the same dict for a CompiledProgram (plan.py's own compiler)"""
+        s = compiled.struct
+        return dict(code=[[compiled.code[i].op, compiled.code[i].argt, compiled.code[i].arg0]
+                          for i in range(s.code_len)],
+                    static=bytes(compiled.static[:s.static_storage_len]).hex(),
+                    method_call=s.method_call, method_accumulate=s.method_accumulate,
+                    return_type=s.return_type, aggregate_fn=s.aggregate_fn)
+
+
+class DumpedPlan:
+    """evql_plan_desc_t assembled from dumped programs: {"scan_columns": [[name, stype]],
+    "where": prog|None, "scan_select": [prog], "group": [prog], "select": [prog]}"""
+
+    def __init__(self, dump, mode=K.MODE_FINAL, scan_mode=K.SCAN_FLAT, groups_hint=0):
+        names = [c[0] for c in dump["scan_columns"]]
+        self.scan_columns = names
+        self.where = RawProgram(dump["where"]) if dump.get("where") else None
+        self.scan_select = [RawProgram(p) for p in dump["scan_select"]]
+        self.group = [RawProgram(p) for p in dump["group"]]
+        self.select = [RawProgram(p) for p in dump["select"]]
+        self._names = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        self._types = (C.c_uint32 * max(1, len(names)))(*[c[1] for c in dump["scan_columns"]])
+        self._scan_select = (K.Program * max(1, len(self.scan_select)))(
+            *[p.struct for p in self.scan_select])
+        self._group = (K.Program * max(1, len(self.group)))(*[p.struct for p in self.group])
+        self._select = (K.Program * max(1, len(self.select)))(*[p.struct for p in self.select])
+        d = K.PlanDesc()
+        d.scan_columns = C.cast(self._names, C.POINTER(C.c_char_p))
+        d.scan_column_types = C.cast(self._types, C.POINTER(C.c_uint32))
+        d.n_scan_columns = len(names)
+        d.where = C.pointer(self.where.struct) if self.where is not None else None
+        d.scan_select = C.cast(self._scan_select, C.POINTER(K.Program))
+        d.n_scan_select = len(self.scan_select)
+        d.group_exprs = C.cast(self._group, C.POINTER(K.Program))
+        d.n_group = len(self.group)
+        d.select_exprs = C.cast(self._select, C.POINTER(K.Program))
+        d.n_select = len(self.select)
+        d.group_mode = mode
+        d.scan_mode = scan_mode
+        d.groups_hint = groups_hint
+        self.desc = d
+
+    @property
+    def output_types(self):
+        if self.select:
+            return [p.return_type for p in self.select]
+        return [p.return_type for p in self.scan_select]
+
+
+def dump_of_plan(plan):
+    """a Plan's programs in the dump form, for comparison with the reference's"""
+    return dict(
+        scan_columns=[[n, int(plan._types[i])] for i, n in enumerate(plan.scan_columns)],
+        where=RawProgram.dump_of(plan.where) if plan.where is not None else None,
+        scan_select=[RawProgram.dump_of(p) for p in plan.scan_select],
+        group=[RawProgram.dump_of(p) for p in plan.group],
+        select=[RawProgram.dump_of(p) for p in plan.select])

@@ -1,0 +1,235 @@
+"""The cases of the reference-generated golden fixtures tests/golden/ref_csql_*.json.
+
+Every case is a plan (expression trees, built from a seed or written out here) that
+tests/sqlgen.py renders to SQL.  tests/golden/gen_ref_csql.py ran that SQL through the
+REAL reference engine (oracle/_ref/csql_probe) in this container and committed what
+came back: result rows, the compiled vm::Programs of the GROUP BY and of the scan
+(lowered by the reference-side adapter), and the PartialGroupByExpression rows.  The
+tests rebuild the same plans from this module, so nothing of the reference is needed
+where they run.
+"""
+import random
+
+import numpy as np
+
+from eventql_amd import capi as K
+from eventql_amd.plan import Col, Lit, Call, If, Agg
+import sqlgen
+import tables as T
+from test_gpu_fuzz import Gen, NestedGen
+
+
+class RefGen(Gen):
+    """Gen restricted to what this snapshot of the reference implements: count,
+    count_distinct(uint64), sum(uint64) (sql/defaults.cc:49-54); no float sums,
+    min, max or mean; count(<string>) is a type error in the reference
+    (conversion.cc:76-79 declares to_nil_string with a BOOL argument)"""
+    count_cols = ()
+
+    def aggregate(self):
+        r = self.r
+        c = r.random()
+        if c < 0.25:
+            return Agg("count", Lit(1))
+        if c < 0.4:
+            return Agg("count", Col(r.choice(self.count_cols or self.uint_cols)))
+        if c < 0.5:
+            return Agg("count_distinct", self.uint())
+        if c < 0.9:
+            return Agg("sum", self.uint())
+        # post-aggregate arithmetic and IF inside the argument
+        if r.random() < 0.5:
+            return Call("add", Agg("sum", self.uint()), Lit(r.choice(self.lits)))
+        return Agg("sum", If(self.boolean(1), Lit(1), Lit(0)))
+
+    def plan_kwargs(self, row_ends):
+        kw = Gen.plan_kwargs(self, row_ends)
+        kw.pop("row_end", None)      # API-level (setFilter / partition slices), not SQL
+        kw.pop("row_filter", None)
+        return kw
+
+
+class RefNestedGen(NestedGen, RefGen):
+    aggregate = RefGen.aggregate
+
+    def plan_kwargs(self, row_ends):
+        kw = NestedGen.plan_kwargs(self, row_ends)
+        kw.pop("row_end", None)
+        kw.pop("row_filter", None)
+        return kw
+
+
+MIXED = dict(uint_cols=["k", "a", "b", "n", "p", "k10", "nb", "w"], float_cols=["v", "nv"],
+             bool_cols=["f"], key_cols=["k", "k10", "f", "nb", "n", "s", "ns", "b"],
+             first_cols=["a", "v", "s"], lits=[0, 1, 2, 7, 1000, 30000, 65535, 1 << 40])
+MIXED_COUNT_COLS = ["k", "a", "n", "nb", "v", "nv", "f", "t"]
+
+SUITES = {}
+
+
+def suite(name):
+    def deco(fn):
+        SUITES[name] = fn
+        return fn
+    return deco
+
+
+def table_image(key):
+    """(cstable image bytes, schema, probe scan kind) of a fixture table"""
+    import nested_tables as N
+    if key == "mixed":
+        return T.mixed_table(300_000)[0], T.MIXED_SCHEMA, "fast"
+    if key == "ranges":
+        return T.ranges_table(), T.RANGES_SCHEMA, "fast"
+    if key == "survey":
+        return T.survey_table(1_000_000)[0], T.SURVEY_SCHEMA, "fast"
+    if key == "items":
+        return N.items_table(50_000)[0], N.ITEMS_SCHEMA, "dremel"
+    if key == "testtbl":
+        # the reference's own checked-in fixture, read as the v0.1.0 file it is
+        return open(T.GOLDEN + "/testtbl.cst", "rb").read(), N.NESTED_SCHEMA, "dremel"
+    raise KeyError(key)
+
+
+def _case(cid, table, kw, schema, scan_mode=K.SCAN_FLAT):
+    """None when the plan cannot be expressed in the reference's SQL"""
+    try:
+        kw = sqlgen.make_runnable(kw, schema, scan_order=(scan_mode != K.SCAN_FLAT))
+        sql = sqlgen.sql_of(kw, "t")
+    except (sqlgen.NotRenderable, sqlgen.FoldError):
+        return None
+    return dict(id=cid, table=table, kw=kw, sql=sql, scan_mode=scan_mode)
+
+
+@suite("mixed")
+def mixed_cases():
+    _, schema, _ = None, T.MIXED_SCHEMA, None
+    out = []
+    for seed in range(120):
+        g = RefGen(50_000 + seed, **MIXED)
+        g.count_cols = MIXED_COUNT_COLS
+        c = _case("mixed-%03d" % seed, "mixed", g.plan_kwargs([1]), T.MIXED_SCHEMA)
+        if c:
+            out.append(c)
+    return out
+
+
+@suite("ranges")
+def ranges_cases():
+    out = []
+    for seed in range(60):
+        g = RefGen(60_000 + seed, **T.RANGES)
+        c = _case("ranges-%03d" % seed, "ranges", g.plan_kwargs([1]), T.RANGES_SCHEMA)
+        if c:
+            out.append(c)
+    return out
+
+
+def _c(name):
+    return Col(name)
+
+
+@suite("survey")
+def survey_cases():
+    """BASELINE.json's configs on the 1M-row SURVEY 8c(ii) table, and every scalar of
+    tests/golden/survey_8c.json as a regenerable case"""
+    a, b, k, n, s, v = [_c(x) for x in "abknsv"]
+    f3 = Call("logical_and", Call("gt", a, Lit(30000)), Call("lt", b, Lit(30000)))
+    cases = [
+        ("config1-count", dict(select=[Agg("count", Lit(1))], group_by=[])),
+        ("config2-int-twin", dict(select=[k, Agg("sum", a), Agg("count", Lit(1))], group_by=[k])),
+        ("config3", dict(select=[k, Agg("sum", a), Agg("count", Lit(1)), Agg("sum", b)],
+                         group_by=[k], where=f3)),
+        ("config3-count-only", dict(select=[Agg("count", Lit(1))], group_by=[], where=f3)),
+        ("config4-string-keys", dict(select=[s, Agg("count", Lit(1)), Agg("sum", a), Agg("sum", b)],
+                                     group_by=[s])),
+        ("config4-high-card", dict(select=[Call("mod", Call("mul", a, b), Lit(666667)),
+                                           Agg("count", Lit(1)), Agg("sum", a)],
+                                   group_by=[Call("mod", Call("mul", a, b), Lit(666667))])),
+        ("null-sum-count", dict(select=[Agg("sum", n), Agg("count", n)], group_by=[],
+                                where=Call("gte", n, Lit(0)))),
+        ("null-compares-as-zero", dict(select=[Agg("count", Lit(1))], group_by=[],
+                                       where=Call("gt", n, Lit(5)))),
+        ("not-or", dict(select=[Agg("count", Lit(1))], group_by=[],
+                        where=Call("logical_or", Call("neg", Call("gt", a, Lit(30000))),
+                                   Call("eq", b, Lit(5))))),
+        ("null-group", dict(select=[n, Agg("count", Lit(1))], group_by=[n],
+                            where=Call("lt", n, Lit(10)))),
+        ("uint64-wrap", dict(select=[Agg("sum", Call("mul", b, Lit(1 << 48)))], group_by=[],
+                             where=Call("gte", b, Lit(0)))),
+        ("sum-if", dict(select=[k, Agg("sum", If(Call("gt", a, Lit(30000)), Lit(1), Lit(0)))],
+                        group_by=[k], where=Call("gte", a, Lit(0)))),
+        ("one-instance-quirk", dict(select=[k, Call("add", Agg("sum", a), Agg("sum", b))],
+                                    group_by=[k],
+                                    where=Call("logical_and", Call("gte", a, Lit(0)),
+                                               Call("gte", b, Lit(0))))),
+        ("multi-key", dict(select=[k, s, Agg("count", Lit(1)), Agg("sum", a)], group_by=[k, s],
+                           where=Call("gte", a, Lit(0)))),
+        ("first-row", dict(select=[k, a, v, s, Agg("count", Lit(1))], group_by=[k],
+                           where=Call("logical_and", Call("gte", a, Lit(0)),
+                                      Call("logical_and", Call("gte", v, Lit(0.0)),
+                                           Call("neq", s, Lit("")))))),
+        ("zero-rows", dict(select=[Agg("count", Lit(1))], group_by=[],
+                           where=Call("gt", v, Lit(8000000.5)))),
+        ("count-distinct", dict(select=[k, Agg("count_distinct", a)], group_by=[k],
+                                where=Call("gte", a, Lit(0)))),
+        ("float-predicate", dict(select=[Call("mod", k, Lit(7)), Agg("count", Lit(1))],
+                                 group_by=[Call("mod", k, Lit(7))],
+                                 where=Call("lt", Call("mul", v, Lit(2.0)), Lit(8000.5)))),
+        ("string-predicate", dict(select=[Agg("count", Lit(1)), Agg("sum", a)], group_by=[],
+                                  where=Call("logical_and", Call("gte", s, Lit("g5")),
+                                             Call("gte", a, Lit(0))))),
+    ]
+    out = []
+    for cid, kw in cases:
+        c = _case("survey-" + cid, "survey", kw, T.SURVEY_SCHEMA)
+        assert c is not None, cid
+        out.append(c)
+    return out
+
+
+ITEMS = dict(uint_cols=["id", "items.position", "items.price"], float_cols=["score"],
+             bool_cols=[], key_cols=["items.position", "id"], first_cols=["items.price", "id"],
+             lits=[0, 1, 3, 7, 1000, 50000, 1 << 33])
+TESTTBL = dict(uint_cols=["time", "event.search_query.time",
+                          "event.search_query.num_result_items",
+                          "event.search_query.result_items.position"],
+               float_cols=[], bool_cols=["event.search_query.result_items.clicked"],
+               key_cols=["event.search_query.result_items.position",
+                         "event.search_query.num_result_items",
+                         "event.search_query.result_items.clicked"],
+               first_cols=["time", "event.search_query.num_result_items"],
+               lits=[0, 1, 2, 6, 10, 1438055327])
+
+
+@suite("nested")
+def nested_cases():
+    """CSTableScan (Dremel assembly), AggregationStrategy::NO_AGGREGATION"""
+    import nested_tables as N
+    out = []
+    for seed in range(80):
+        which = seed % 2
+        table, schema, cols = (("items", N.ITEMS_SCHEMA, ITEMS) if which == 0 else
+                               ("testtbl", N.NESTED_SCHEMA, TESTTBL))
+        g = RefNestedGen(70_000 + seed, **cols)
+        g.count_cols = list(cols["uint_cols"]) + list(cols["bool_cols"])
+        if which == 0:
+            g.leaf_uint, g.leaf_bool = ["items.position", "items.price"], []
+        else:
+            g.leaf_uint = ["event.search_query.result_items.position"]
+            g.leaf_bool = ["event.search_query.result_items.clicked"]
+        c = _case("nested-%03d" % seed, table, g.plan_kwargs([1]), schema,
+                  scan_mode=K.SCAN_NESTED)
+        if c:
+            out.append(c)
+    return out
+
+
+def all_cases():
+    return {name: fn() for name, fn in SUITES.items()}
+
+
+def table_schema(key):
+    import nested_tables as N
+    return {"mixed": T.MIXED_SCHEMA, "ranges": T.RANGES_SCHEMA, "survey": T.SURVEY_SCHEMA,
+            "items": N.ITEMS_SCHEMA, "testtbl": N.NESTED_SCHEMA}[key]

@@ -317,46 +317,7 @@ def test_random_within_record_plan(nested, seed):
 
 
 # ---- full-range columns -------------------------------------------------------------------
-RANGES_SCHEMA = dict(x17=K.T_UINT64, x24=K.T_UINT64, x31=K.T_UINT64, x32=K.T_UINT64,
-                     p32=K.T_UINT64, q64=K.T_UINT64, l64=K.T_UINT64, g=K.T_UINT64,
-                     fv=K.T_FLOAT64, nx24=K.T_UINT64)
-RANGES = dict(uint_cols=["x17", "x24", "x31", "x32", "p32", "q64", "l64", "g", "nx24"],
-              float_cols=["fv"], bool_cols=[], key_cols=["g", "x17", "nx24"],
-              first_cols=["x24", "q64", "fv"],
-              lits=[1, 3, 13, 255, 65536, (1 << 24) - 1, (1 << 31) + 5, (1 << 32) - 1, 1 << 63])
-
-
-def ranges_table(n=200_000):
-    rng = np.random.default_rng(77)
-
-    def edgy(bits):
-        # uniform, plus a third of the rows within 40 of the top of the range
-        top = (1 << bits) - 1
-        v = rng.integers(0, top, n, dtype=np.uint64, endpoint=True)
-        near = np.uint64(top) - rng.integers(0, 40, n, dtype=np.uint64)
-        return np.where(rng.random(n) < 0.33, near, v).astype(np.uint64)
-
-    c = dict(x17=edgy(17), x24=edgy(24), x31=edgy(31), x32=edgy(32), p32=edgy(32),
-             q64=edgy(64), l64=edgy(64), g=rng.integers(0, 37, n, dtype=np.uint64),
-             fv=rng.normal(0, 1e6, n), nx24=edgy(24))
-    pres = (rng.random(n) < 0.8).astype(np.uint8)
-    bp = lambda name, bits, **kw: dict(name=name, logical_type=K.COL_UNSIGNED_INT,
-                                       storage_type=K.ENC_UINT32_BITPACKED,
-                                       bitpack_max_value=(1 << bits) - 1, **kw)
-    w = E.Writer([bp("x17", 17), bp("x24", 24), bp("x31", 31), bp("x32", 32),
-                  dict(name="p32", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT32_PLAIN),
-                  dict(name="q64", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
-                  dict(name="l64", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_LEB128),
-                  bp("g", 6),
-                  dict(name="fv", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754),
-                  bp("nx24", 24, dlevel_max=1)])
-    for name in ("x17", "x24", "x31", "x32", "p32", "q64", "l64", "g", "fv"):
-        w.put(name, c[name])
-    w.put("nx24", c["nx24"], present=pres)
-    w.commit(n)
-    img = w.image()
-    w.close()
-    return img
+RANGES_SCHEMA, RANGES, ranges_table = T.RANGES_SCHEMA, T.RANGES, T.ranges_table
 
 
 @pytest.fixture(scope="module")

@@ -1,0 +1,174 @@
+"""HIP path vs the REAL reference engine.
+
+(1) Every case of tests/golden/ref_csql_*.json (results of the reference's own
+    csql::Runtime, see test_ref_csql_cpu.py) run through the C ABI on the MI355X, from
+    plan.py's programs and from the reference compiler's dumped programs: result rows
+    bit for bit, error class, PartialGroupBy rows byte for byte.
+
+(2) The drop-in, end to end: oracle/_ref/csql_probe is the reference's own engine
+    (parser, planner, ResultCursor, CPU operators) linked with the reference-side adapter
+    eventql_amd/adapter/ and libevql_mi355x.so.  It was compiled in the build container
+    (oracle/ref_csql/build.sh) and travels here as a binary.  With `MODE gpu` the
+    reference's scheduler hook (DefaultScheduler::buildGroupByExpression, scheduler.h:78-173)
+    returns the fused MI355X operator; the same SQL text must give the rows the
+    unmodified CPU operators gave.
+"""
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import eventql_amd as E
+from eventql_amd import capi as K
+from eventql_amd.plan import Plan, DumpedPlan
+import refcases
+import sqlgen
+import tables as T
+from test_ref_csql_cpu import (SUITES, load, fixture_case, case_plan, check_result,
+                               check_partial, all_lowerable, _param_cases)
+
+pytestmark = pytest.mark.gpu
+
+PROBE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                     "oracle", "_ref", "csql_probe")
+
+_tables = {}
+
+
+@pytest.fixture(scope="module")
+def gpu_tables(ctx):
+    def get(key):
+        if key not in _tables:
+            img, schema, _ = refcases.table_image(key)
+            _tables[key] = (ctx.open_image(img), schema)
+        return _tables[key]
+    yield get
+    for t, _ in _tables.values():
+        t.close()
+    _tables.clear()
+
+
+def run_gpu(t, plan):
+    """-> (types, rows) | error message | None when not lowerable"""
+    try:
+        q = t.query(plan)
+    except E.EvqlError as e:
+        if e.code == K.EVQL_ENOTSUP:
+            return None
+        raise
+    try:
+        try:
+            r = q.run()
+        except E.EvqlError as e:
+            return e.msg
+        return (r.types, r.rows())
+    finally:
+        q.close()
+
+
+@pytest.mark.parametrize("suite,cid", _param_cases())
+def test_hip_path_reproduces_the_reference(gpu_tables, suite, cid):
+    fx = fixture_case(suite, cid)
+    c = case_plan(suite, cid)
+    if "programs" not in fx:
+        pytest.skip("rejected by the reference's planner")
+    if fx["result"].get("ok") is None:
+        pytest.skip("reference behaviour undefined here")
+    t, schema = gpu_tables(c["table"])
+    plan = Plan(schema, scan_mode=c["scan_mode"], **c["kw"])
+    r = run_gpu(t, plan)
+    if r is None:
+        pytest.skip("not lowerable (EVQL_ENOTSUP): the CPU operators keep this plan")
+    check_result(fx["result"], r)
+    if all_lowerable(fx["programs"]):
+        r2 = run_gpu(t, DumpedPlan(fx["programs"], scan_mode=c["scan_mode"]))
+        assert r2 is not None
+        check_result(fx["result"], r2)
+    if fx["partial"]["ok"] and fx["result"]["ok"] and c["scan_mode"] == K.SCAN_FLAT:
+        try:
+            q = t.query(Plan(schema, mode=K.MODE_PARTIAL, scan_mode=c["scan_mode"], **c["kw"]))
+        except E.EvqlError as e:
+            assert e.code == K.EVQL_ENOTSUP, e
+            return
+        try:
+            got = q.run()
+            rows = got.rows()
+            check_partial(fx["partial"], [k for k, _ in rows], [d for _, d in rows])
+        finally:
+            q.close()
+
+
+def test_lowered_share(gpu_tables):
+    """the flat suites must actually run on the device, not skip their way to green"""
+    lowered = total = 0
+    for suite in ("survey", "mixed", "ranges"):
+        for fx in load(suite)["cases"]:
+            if "programs" not in fx:
+                continue
+            c = case_plan(suite, fx["id"])
+            t, schema = gpu_tables(c["table"])
+            total += 1
+            try:
+                q = t.query(Plan(schema, scan_mode=c["scan_mode"], **c["kw"]))
+                q.close()
+                lowered += 1
+            except E.EvqlError as e:
+                assert e.code == K.EVQL_ENOTSUP, e
+    assert lowered >= 0.9 * total, (lowered, total)
+
+
+# ---------------------------------------------------------------------------------------
+# (2) the reference's own engine with the GPU operator plugged in
+# ---------------------------------------------------------------------------------------
+def probe_rows(res):
+    """probe cells are already canonical (floats as "f:<bits>"); sort like canon_rows"""
+    def key(r):
+        return [(0, "") if c is None else (1, repr(c)) for c in r]
+    rows = [list(r) for r in res["rows"]]
+    rows.sort(key=key)
+    return rows
+
+
+@pytest.mark.skipif(not os.path.exists(PROBE), reason="oracle/_ref/csql_probe not built "
+                    "(needs /root/reference at build time)")
+@pytest.mark.parametrize("suite", SUITES)
+def test_reference_engine_with_gpu_operator(suite):
+    fx = load(suite)
+    cases = [c for c in fx["cases"] if "programs" in c and c["result"].get("ok") is not None]
+    by_table = {}
+    for c in cases:
+        by_table.setdefault(c["table"], []).append(c)
+    lowered = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for table, cs in by_table.items():
+            img, _, kind = refcases.table_image(table)
+            path = os.path.join(tmp, table + ".cst")
+            with open(path, "wb") as f:
+                f.write(img)
+            cmds = ["TABLE t %s %s" % (path, kind), "ROWS on", "MODE gpu"]
+            cmds += ["SQL " + c["sql"] for c in cs]
+            p = subprocess.run([PROBE], input="\n".join(cmds) + "\n", capture_output=True,
+                               text=True, timeout=900)
+            assert p.returncode == 0, p.stderr[-2000:]
+            res = [json.loads(l) for l in p.stdout.splitlines() if l.strip()]
+            assert len(res) == len(cs)
+            for c, r in zip(cs, res):
+                assert r["sql"] == c["sql"]
+                want = c["result"]
+                d = [x for x in r.get("decisions", []) if x["node"] == "groupby"]
+                if d and d[0]["lowered"]:
+                    lowered += 1
+                if not want["ok"]:
+                    assert not r["ok"], c["id"]
+                    assert ("zero" in want["error"]) == ("zero" in r["error"]), (c["id"], r["error"])
+                    continue
+                assert r["ok"], (c["id"], r.get("error"))
+                assert r["types"] == want["types"], c["id"]
+                rows = probe_rows(r)
+                assert len(rows) == want["nrows"], c["id"]
+                assert rows[:len(want["rows"])] == want["rows"], c["id"]
+                assert sqlgen.rows_digest(rows) == want["digest"], c["id"]
+    # the GPU operator, not the CPU fallback, produced (most of) these
+    assert lowered >= (0.9 if suite != "nested" else 0.3) * len(cases), (lowered, len(cases))
