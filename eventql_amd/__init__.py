@@ -80,6 +80,7 @@ def lib():
     L.evql_writer_image.restype = C.c_void_p
     L.evql_writer_image.argtypes = [C.c_void_p, _u64p]
     L.evql_cstable_upgrade.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
+    L.evql_cstable_inspect.argtypes = [C.c_char_p, C.c_uint64, _u64p, C.POINTER(C.c_int)]
     L.evql_writer_write_file.argtypes = [C.c_void_p, C.c_char_p]
     L.evql_writer_destroy.argtypes = [C.c_void_p]
     L.evql_query_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(K.PlanDesc),
@@ -136,6 +137,16 @@ def _check(rc):
 
 def _ptr(a, ty):
     return a.ctypes.data_as(ty) if a is not None else None
+
+
+def inspect_image(image):
+    """(num_rows, num_columns) of a cstable image, or EvqlError(EVQL_EIO) for a
+    truncated / corrupt one (evql_cstable_inspect; host-only)"""
+    buf = bytes(image)
+    n = C.c_uint64(0)
+    nc = C.c_int(0)
+    _check(lib().evql_cstable_inspect(buf, len(buf), C.byref(n), C.byref(nc)))
+    return n.value, nc.value
 
 
 def upgrade_image(image):

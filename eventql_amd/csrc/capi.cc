@@ -472,6 +472,27 @@ int evql_cstable_upgrade(const void* image, uint64_t len, void* dst, uint64_t ds
   return EVQL_OK;
 }
 
+int evql_cstable_inspect(const void* image, uint64_t len, uint64_t* num_rows, int* num_columns) {
+  API_TRY
+  if (!image) return fail(EVQL_EARG, "null argument");
+  const uint8_t* b = static_cast<const uint8_t*>(image);
+  std::vector<uint8_t> v2;
+  if (len >= 6 && b[0] == 0x23 && b[1] == 0x17 && b[2] == 0x23 && b[3] == 0x17 &&
+      (uint32_t(b[4]) | (uint32_t(b[5]) << 8)) == 1) {
+    std::string e = transcode_v1_to_v2(b, len, &v2);
+    if (!e.empty()) return fail(EVQL_EIO, e);
+    b = v2.data();
+    len = v2.size();
+  }
+  TableLayout layout;
+  std::string e = parse_cstable(b, len, &layout);
+  if (!e.empty()) return fail(EVQL_EIO, e);
+  if (num_rows) *num_rows = layout.num_rows;
+  if (num_columns) *num_columns = int(layout.columns.size());
+  return EVQL_OK;
+  API_CATCH
+}
+
 int evql_writer_write_file(const evql_writer_t* w, const char* path) {
   std::string e = w->w->write_file(path);
   if (!e.empty()) return fail(EVQL_EIO, e);
@@ -589,6 +610,11 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
                              uint64_t* n_groups) {
   API_TRY
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
+  if (q->kp.need_first_row) {
+    // a first-row index means something only inside the table that produced it:
+    // key / select values of such plans travel with evql_query_export_resolved
+    return fail(EVQL_ENOTSUP, "plan reads first-row values: use evql_query_export_resolved");
+  }
   hipStream_t s = q->ctx->stream;
   if (!q->d_gtab || !q->d_counters) return fail(EVQL_EARG, "execute() was not called");
   uint64_t* d_cnt = q->d_counters + 6;  // per-query counter block: no allocation per call

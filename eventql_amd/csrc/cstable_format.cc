@@ -59,7 +59,7 @@ struct Cursor {
   }
   std::string lenenc_string() {
     uint64_t n = varuint();
-    if (!ok || pos + n > len) {
+    if (!ok || pos > len || n > len - pos) {  // (pos + n may wrap)
       ok = false;
       return std::string();
     }
@@ -119,7 +119,8 @@ std::string parse_cstable(const uint8_t* image, size_t len, TableLayout* out) {
   }
   if (!c.ok) return "corrupt cstable header";
 
-  if (out->index_offset + out->index_size > len) {
+  // (u64 sums of file-supplied numbers may wrap: compare without adding)
+  if (out->index_offset > len || out->index_size > len - out->index_offset) {
     return "corrupt cstable: index out of bounds";
   }
   Cursor ic{image + out->index_offset, out->index_size, 0, true};
@@ -131,7 +132,7 @@ std::string parse_cstable(const uint8_t* image, size_t len, TableLayout* out) {
     pr.offset = ic.varuint();
     pr.size = uint32_t(ic.varuint());
     if (!ic.ok) break;
-    if (pr.offset + pr.size > len) return "corrupt cstable: page out of bounds";
+    if (pr.offset > len || pr.size > len - pr.offset) return "corrupt cstable: page out of bounds";
     for (auto& col : out->columns) {
       if (col.column_id != cid) continue;
       switch (PageKind(kind)) {
@@ -148,6 +149,68 @@ std::string parse_cstable(const uint8_t* image, size_t len, TableLayout* out) {
     }
   }
   if (!ic.ok) return "corrupt cstable index";
+  return validate_layout(image, len, *out);
+}
+
+// The kernels (and the host-side string walk) address pages by the fixed geometry
+// the reference's writers produce -- 512 KiB PLAIN / LEB128 / STRING pages
+// (page_writer_uint64.h:34), bit-packed pages of 1024 blocks with the u32 max_value
+// in front of the first (page_writer_bitpacked.cc:43-60) -- and flat required
+// streams by row number.  A file that breaks these would send them out of bounds;
+// the reference's readers fail on such files with "end of column reached".
+std::string validate_layout(const uint8_t* image, size_t len, const TableLayout& t) {
+  (void) len;
+  auto bitpacked_capacity = [&](const std::vector<PageRef>& pages, uint64_t* cap) -> bool {
+    *cap = ~0ull;  // width 0: every value is 0, no pages needed
+    if (pages.empty()) return true;
+    if (pages[0].size < 4) return false;
+    uint32_t maxv;
+    memcpy(&maxv, image + pages[0].offset, 4);
+    const uint32_t b = bitpack_width(maxv);
+    if (b == 0) return false;  // a width-0 stream has no pages
+    const uint64_t page_bytes = 16ull * b * kBitpackBlocksPerPage;
+    for (size_t i = 0; i < pages.size(); ++i) {
+      if (pages[i].size != page_bytes + (i == 0 ? 4 : 0)) return false;
+    }
+    *cap = uint64_t(pages.size()) * kBitpackBlocksPerPage * 128;
+    return true;
+  };
+  for (const auto& c : t.columns) {
+    uint64_t cap = 0;
+    const bool flat_required = c.rlevel_max == 0 && c.dlevel_max == 0;
+    switch (c.storage_type) {
+      case ColumnEncoding::UINT32_BITPACKED:
+      case ColumnEncoding::BOOLEAN_BITPACKED:
+        if (!bitpacked_capacity(c.data_pages, &cap)) {
+          return "corrupt cstable: bad bit-packed page geometry in column " + c.name;
+        }
+        break;
+      default: {
+        for (const auto& p : c.data_pages) {
+          if (p.size != kPlainPageSize) {
+            return "corrupt cstable: bad page size in column " + c.name;
+          }
+        }
+        const uint64_t per_page =
+            c.storage_type == ColumnEncoding::UINT32_PLAIN ? kPlainPageSize / 4 : kPlainPageSize / 8;
+        cap = uint64_t(c.data_pages.size()) * per_page;
+        if (c.storage_type == ColumnEncoding::UINT64_LEB128 ||
+            c.storage_type == ColumnEncoding::STRING_PLAIN) {
+          // at least one byte per value
+          cap = uint64_t(c.data_pages.size()) * kPlainPageSize;
+        }
+      }
+    }
+    if (flat_required && cap < t.num_rows) return "corrupt cstable: end of column reached: " + c.name;
+    uint64_t lcap = 0;
+    if (!bitpacked_capacity(c.rlevel_pages, &lcap) || !bitpacked_capacity(c.dlevel_pages, &lcap)) {
+      return "corrupt cstable: bad level page geometry in column " + c.name;
+    }
+    // (lcap is the definition level stream's here)
+    if (c.rlevel_max == 0 && c.dlevel_max > 0 && lcap < t.num_rows) {
+      return "corrupt cstable: end of column reached: " + c.name;
+    }
+  }
   return std::string();
 }
 

@@ -78,6 +78,8 @@ uint32_t bitpack_width(uint32_t max_value);
 
 // Parses a v0.2.0 image.  Returns "" on success, else an error message.
 std::string parse_cstable(const uint8_t* image, size_t len, TableLayout* out);
+// page geometry / capacity checks of a parsed layout ("" = fine); parse_cstable runs it
+std::string validate_layout(const uint8_t* image, size_t len, const TableLayout& t);
 
 // Re-encodes a v0.1.0 image as v0.2.0 (cstable_v1.cc).  Returns "" on success.
 std::string transcode_v1_to_v2(const uint8_t* image, size_t len, std::vector<uint8_t>* out);

@@ -224,6 +224,51 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     }
     kp.cols.push_back(c);
   }
+  if (nested && !kp.cols.empty()) {
+    // Every referenced column must lie on the leaf's ancestor chain: k_flatten_parent
+    // indexes a shallower column's slots with counts taken from the LEAF's repetition
+    // levels, which is meaningless for a column of a sibling repeated group (the
+    // reference zips such groups).  The v0.2.0 header holds no tree,
+    // so the chain is checked on the dotted names: the number of repeated nodes on
+    // the common ancestor path P of a column A and the leaf is at most
+    // min{rlevel_max(C) : C below P}; A's repeated ancestors are all on P only if
+    // that bound reaches rlevel_max(A).  (materialize_nested adds an exact check on
+    // the slot counts.)
+    size_t leaf = 0;
+    for (size_t i = 0; i < kp.cols.size(); ++i) {
+      if (layout.columns[kp.cols[i].layout_index].rlevel_max >
+          layout.columns[kp.cols[leaf].layout_index].rlevel_max) {
+        leaf = i;
+      }
+    }
+    const ColumnLayout& lc = layout.columns[kp.cols[leaf].layout_index];
+    auto parent_path = [](const std::string& a, const std::string& b) {
+      // longest common prefix of a and b that ends at a '.' of both ("" = root);
+      // identical names share the whole name
+      if (a == b) return a;
+      size_t n = 0, last = 0;
+      while (n < a.size() && n < b.size() && a[n] == b[n]) {
+        if (a[n] == '.') last = n;
+        ++n;
+      }
+      return a.substr(0, last);
+    };
+    for (const auto& c : kp.cols) {
+      const ColumnLayout& cl = layout.columns[c.layout_index];
+      if (cl.rlevel_max == 0 || &cl == &lc) continue;
+      const std::string p = parent_path(cl.name, lc.name);
+      uint32_t bound = ~0u;
+      for (const auto& other : layout.columns) {
+        const bool below = p.empty() || other.name == p ||
+                           (other.name.size() > p.size() && other.name[p.size()] == '.' &&
+                            other.name.compare(0, p.size(), p) == 0);
+        if (below && other.rlevel_max < bound) bound = other.rlevel_max;
+      }
+      if (bound < cl.rlevel_max) {
+        return unsup("nested columns from different repeated groups: " + cl.name + ", " + lc.name);
+      }
+    }
+  }
   if (nested && plan->where) {
     // after a row rejected by WHERE the reference resets parent values without
     // re-reading them (CSTableScan.cc:501-512); only leaf-level-only scans are

@@ -343,6 +343,24 @@ static Status upload_string_positions(evql_table* t, MaterializedColumn* m) {
   return Status();
 }
 
+// values the data pages of a fixed-width encoding can hold (byte streams: no bound,
+// their decoders stop at the end of the stream)
+static uint64_t fixed_width_capacity(const ColumnLayout& c) {
+  switch (c.storage_type) {
+    case ColumnEncoding::UINT64_PLAIN:
+    case ColumnEncoding::FLOAT_IEEE754:
+      return uint64_t(c.data_pages.size()) * (kPlainPageSize / 8);
+    case ColumnEncoding::UINT32_PLAIN:
+      return uint64_t(c.data_pages.size()) * (kPlainPageSize / 4);
+    case ColumnEncoding::UINT32_BITPACKED:
+    case ColumnEncoding::BOOLEAN_BITPACKED:
+      return c.data_pages.empty() ? ~0ull
+                                  : uint64_t(c.data_pages.size()) * kBitpackBlocksPerPage * 128;
+    default:
+      return ~0ull;
+  }
+}
+
 static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* bits_out) {
   evql_ctx* ctx = t->ctx;
   const ColumnLayout& c = t->layout.columns[ca.layout_index];
@@ -406,6 +424,11 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
     HIP_TRY(hipStreamSynchronize(s));
   }
 
+  if (nvalues > fixed_width_capacity(c)) {
+    // fewer data pages than defined values (column_reader_uint.cc raises
+    // "end of column reached" when it gets there)
+    return Status::error(EVQL_EIO, "end of column reached: " + c.name);
+  }
   switch (c.storage_type) {
     case ColumnEncoding::UINT64_PLAIN:
     case ColumnEncoding::FLOAT_IEEE754:
@@ -598,6 +621,9 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
     HIP_TRY(hipMemcpyAsync(d_tiles, offs.data(), (ntiles + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
+  if (nvalues > fixed_width_capacity(c)) {
+    return Status::error(EVQL_EIO, "end of column reached: " + c.name);
+  }
   RtColumn src{};
   src.pages = t->d_pages[li][0];
   DevBuf<uint64_t> d_dense;
@@ -648,6 +674,49 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
 
 using LeafLevels = evql_table::LeafLevels;
 
+// number of (r, d, value) slots a repeated column holds for the table's records:
+// where record number `num_rows` would start in its (zero-padded) repetition levels
+static Status exact_slot_count(evql_table* t, int li, uint64_t* out) {
+  const ColumnLayout& c = t->layout.columns[li];
+  const uint64_t nrec = t->layout.num_rows;
+  if (c.rlevel_max == 0) {
+    *out = nrec;
+    return Status();
+  }
+  hipStream_t s = t->ctx->stream;
+  uint32_t rbits = 0;
+  Status st = stream_bits(t, c.rlevel_pages, &rbits);
+  if (!st.ok()) return st;
+  if (rbits == 0) return Status::error(EVQL_ENOTSUP, "repeated column without repetition levels");
+  const uint64_t cap = level_stream_capacity(c.rlevel_pages, rbits);
+  const uint64_t capp = padded_rows(cap);
+  const uint64_t ntiles = (cap + kDecodeTile - 1) / kDecodeTile;
+  DevBuf<uint8_t> d_lv;
+  DevBuf<uint64_t> d_cnt, d_n;
+  HIP_TRY(d_lv.alloc(capp));
+  HIP_TRY(hipMemsetAsync(d_lv, 0xff, capp, s));
+  HIP_TRY(d_cnt.alloc((ntiles + 2) * 8));
+  HIP_TRY(d_n.alloc(8));
+  LevelDecodeArgs la{};
+  la.image = t->d_image;
+  la.pages = t->d_pages[li][1];
+  la.bits = rbits;
+  la.nslots = cap;
+  la.levels = d_lv;
+  for (int k = 0; k < 4; ++k) la.thr[k] = 255;
+  la.counts[0] = d_cnt;
+  la.thr[0] = 0;
+  HIP_TRY(launch_level_decode(la, s));
+  HIP_TRY(launch_exclusive_scan(d_cnt, ntiles, nullptr, s));
+  uint64_t n = cap;
+  HIP_TRY(hipMemcpyAsync(d_n, &n, 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_find_nth(d_lv, d_cnt, cap, 0, nrec, d_n, s));
+  HIP_TRY(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *out = n;
+  return Status();
+}
+
 // flattens `cols` (all of one ancestor chain) to one value per leaf slot:
 // (*flat)[i] is borrowed from the table's nested cache
 static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& cols,
@@ -691,6 +760,7 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
     }
   }
   uint64_t nflat = nrec;
+  uint64_t leaf_cap = 0;
   DevBuf<uint8_t> d_leaf_levels;
   std::vector<uint32_t> thr_levels;       // distinct parent rlevel_max values
   struct OwnedList {                       // scanned per-tile counts per threshold
@@ -705,6 +775,7 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
     Status st = stream_bits(t, lc.rlevel_pages, &rbits);
     if (!st.ok()) return st;
     const uint64_t cap = level_stream_capacity(lc.rlevel_pages, rbits);
+    leaf_cap = cap;
     const uint64_t capp = padded_rows(cap);
     const uint64_t ntiles = (cap + kDecodeTile - 1) / kDecodeTile;
     thr_levels.push_back(0);
@@ -775,6 +846,35 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
     uint64_t cap = 0;
     Status st = nested_slot_values(t, li, nflat, &d_vals.p, &cap);
     if (!st.ok()) return st;
+    if (c.rlevel_max > 0 && li != leaf_li) {
+      // exact ancestor-chain check (the planner's is on names only): a column on the
+      // leaf's chain has one slot per leaf slot whose repetition level does not
+      // exceed the column's depth.  A sibling repeated group passes only by
+      // coincidence of every count.
+      uint64_t own = 0;
+      st = exact_slot_count(t, li, &own);
+      if (!st.ok()) return st;
+      bool chain = false;
+      if (c.rlevel_max >= lc.rlevel_max) {
+        chain = own == nflat;
+      } else {
+        size_t k = 0;
+        while (thr_levels[k] != c.rlevel_max) ++k;
+        // the own-th (0-based) leaf slot with r <= depth must be the first padding slot
+        DevBuf<uint64_t> d_n;
+        HIP_TRY(d_n.alloc(8));
+        uint64_t at = ~0ull;
+        HIP_TRY(hipMemcpyAsync(d_n, &at, 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_find_nth(leaf_levels, thr_offsets[k], leaf_cap, c.rlevel_max, own, d_n, s));
+        HIP_TRY(hipMemcpyAsync(&at, d_n, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // (a leaf stream without a padding slot cannot be probed this way)
+        chain = at == nflat || nflat == leaf_cap;
+      }
+      if (!chain) {
+        return Status::error(EVQL_ENOTSUP, "nested columns from different repeated groups");
+      }
+    }
     if (c.rlevel_max >= lc.rlevel_max) {
       if (padded_rows(cap) < flatp) {
         // level streams shorter than the leaf's: not the same ancestor chain

@@ -300,6 +300,17 @@ const void* evql_writer_image(const evql_writer_t* w, uint64_t* len);
  */
 int evql_cstable_upgrade(const void* image, uint64_t len, void* dst,
                          uint64_t dst_cap, uint64_t* out_len);
+/*
+ * The checks evql_table_open_* run before anything of the file reaches a kernel
+ * (cstable::CSTableReader::openFile, io/cstable/cstable_reader.cc:133-200, plus the
+ * page geometry the device code relies on): magic / version, SHA1-sealed metablock,
+ * header, index within bounds (overflow-safe), every page of the size its encoding
+ * fixes, required flat columns and definition-level streams large enough for
+ * num_rows.  Host-only.  EVQL_EIO + evql_last_error() for a truncated or corrupt
+ * file; the reference raises "end of column reached" when a scan gets that far.
+ */
+int evql_cstable_inspect(const void* image, uint64_t len, uint64_t* num_rows,
+                         int* num_columns);
 int evql_writer_write_file(const evql_writer_t* w, const char* path);
 void evql_writer_destroy(evql_writer_t* w);
 

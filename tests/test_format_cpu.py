@@ -258,3 +258,128 @@ def test_corrupt_files_rejected(tmp_path, built):
     bad = bytearray(img[:4096])
     bad[14 + 48] ^= 0xFF  # break the only valid metablock's checksum input
     assert not L.orc_table_open_image(bytes(bad), len(bad))
+
+
+def test_product_parser_rejects_truncated_and_corrupt_images(built):
+    """parse_cstable must not trust the file.  Truncations at every
+    structural boundary, wrapped u64 offsets, wrong page geometry and too few pages
+    for num_rows all answer EVQL_EIO (the reference: "end of column reached" /
+    "invalid file"); nothing may crash -- this also runs under the ASan build
+    (EVQL_LIB=eventql_amd/libevql_asan.so)."""
+    import struct
+    import numpy as np
+    import eventql_amd as E
+    n = 140_000  # > one bit-packed page (131072 values), > two PLAIN64 pages
+    w = E.Writer([
+        dict(name="u64", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+        dict(name="bp", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT32_BITPACKED,
+             bitpack_max_value=1023),
+        dict(name="nl", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_LEB128,
+             dlevel_max=1),
+        dict(name="s", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN)])
+    i = np.arange(n, dtype=np.uint64)
+    w.put("u64", i)
+    w.put("bp", i % np.uint64(1000))
+    w.put("nl", i, present=(i % np.uint64(3) != 0).astype(np.uint8))
+    w.put("s", [b"x%dx" % k for k in range(n)])
+    w.commit(n)
+    img = bytes(w.image())
+    w.close()
+    assert E.inspect_image(img) == (n, 4)
+
+    def rejected(b):
+        with pytest.raises(E.EvqlError) as ei:
+            E.inspect_image(b)
+        assert ei.value.code == K.EVQL_EIO, ei.value
+        return ei.value.msg
+
+    # truncations: inside the header, the metablocks, the page area, the index
+    for cut in (0, 5, 13, 40, 300, 511, 512, 4096, len(img) // 2, len(img) - 1):
+        rejected(img[:cut])
+    # metablock: txid / num_rows / index_offset / index_size live in the first 28 bytes
+    # of a 48-byte block sealed by SHA1: flipping any of them invalidates the block
+    mb = 14
+    flipped = bytearray(img)
+    flipped[mb + 8] ^= 0xff       # num_rows, slot 0
+    flipped[mb + 48 + 8] ^= 0xff  # num_rows, slot 1
+    assert "metablock" in rejected(bytes(flipped))
+
+    def reseal(b, txid, nrows, ioff, isize):
+        import hashlib
+        body = struct.pack("<QQQI", txid, nrows, ioff, isize)
+        blk = body + hashlib.sha1(body).digest()
+        b = bytearray(b)
+        slot = mb + (txid % 2) * 48
+        b[slot:slot + 48] = blk
+        return bytes(b)
+
+    txid, nrows, ioff, isize = struct.unpack_from("<QQQI", img, mb + 48 * 0)
+    if nrows != n:  # the valid block is the other slot
+        txid, nrows, ioff, isize = struct.unpack_from("<QQQI", img, mb + 48)
+    assert nrows == n
+    # crafted (validly sealed) metablocks
+    assert "index" in rejected(reseal(img, txid + 2, n, (1 << 64) - 8, 64))     # offset + size wraps
+    assert "index" in rejected(reseal(img, txid + 2, n, len(img) - 4, 64))     # runs past the end
+    assert "end of column" in rejected(reseal(img, txid + 2, n * 50, ioff, isize))  # pages too few
+    assert E.inspect_image(reseal(img, txid + 2, n - 5, ioff, isize)) == (n - 5, 4)
+    # index entries: a page whose offset + size wraps / leaves the file, a page of the
+    # wrong size for its encoding
+    idx = bytearray(img[ioff:ioff + isize])
+
+    def varuint(v):
+        out = bytearray()
+        while True:
+            x = v & 0x7f
+            v >>= 7
+            out.append(x | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def index_with(entries):
+        body = varuint(len(entries)) + b"".join(
+            varuint(k) + varuint(c) + varuint(o) + varuint(sz) for k, c, o, sz in entries)
+        b = img[:ioff] + body
+        return reseal(b, txid + 2, n, ioff, len(body))
+
+    def read_index():
+        pos, out = 0, []
+
+        def rd():
+            nonlocal pos
+            v = s = 0
+            while True:
+                x = idx[pos]
+                pos += 1
+                v |= (x & 0x7f) << s
+                s += 7
+                if not x & 0x80:
+                    return v
+        cnt = rd()
+        for _ in range(cnt):
+            out.append((rd(), rd(), rd(), rd()))
+        return out
+
+    entries = read_index()
+    assert E.inspect_image(index_with(entries)) == (n, 4)
+    e0 = list(entries)
+    e0[0] = (e0[0][0], e0[0][1], (1 << 64) - 16, e0[0][3])
+    assert "page out of bounds" in rejected(index_with(e0))
+    e1 = list(entries)
+    e1[0] = (e1[0][0], e1[0][1], e1[0][2], e1[0][3] - 8)
+    assert "page" in rejected(index_with(e1))
+    # dropping the last data page of the PLAIN64 column leaves too few values
+    last_u64 = max(k for k, e in enumerate(entries) if e[0] == 1 and e[1] == entries[0][1]
+                   and entries[0][0] == 1) if entries[0][0] == 1 else None
+    if last_u64 is not None:
+        e2 = [e for k, e in enumerate(entries) if k != last_u64]
+        assert "end of column" in rejected(index_with(e2))
+    # random single-byte corruption of header and index must never crash
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        b = bytearray(img[:ioff + isize])
+        pos = int(rng.integers(0, 600)) if rng.random() < 0.5 else int(ioff + rng.integers(0, isize))
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            E.inspect_image(bytes(b))
+        except E.EvqlError as e:
+            assert e.code == K.EVQL_EIO
