@@ -3,7 +3,7 @@
  *
  * REFERENCE-SIDE ADAPTER: this translation unit includes the reference's headers
  * (sql/runtime/vm.h, sql/expressions/*.h) and therefore compiles only inside a
- * reference build (here: oracle/ref_csql/build.sh, where /root/reference exists).
+ * reference build (in this repository: the test-only reference build, where /root/reference exists).
  * It is the code a maintainer adds under src/eventql/sql/runtime/ to bind
  * libevql_mi355x.so (include/evql_gpu.h); nothing in the product library depends
  * on it.
