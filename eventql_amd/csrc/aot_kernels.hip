@@ -324,18 +324,343 @@ __global__ void __launch_bounds__(kBlock) k_leb128_decode(const u8* image, const
   }
 }
 
-__global__ void k_string_hash(const u8* image, const u64* pages, const u64* offsets,
-                              const u32* lens, u64 n, u64* out) {
+__global__ void k_string_hash(const u8* image, const u64* pages, const u64* strpos, u64 n,
+                              u64* out) {
   for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (u64) gridDim.x * blockDim.x) {
-    const u64 off = offsets[i];
-    const u32 len = lens[i];
+    const u64 sp = strpos[i];
+    const u64 off = sp & 0xffffffffffull;
+    const u32 len = (u32) (sp >> 40);
     u64 h = 0xcbf29ce484222325ull ^ ((u64) len * 0x9e3779b97f4a7c15ull);
     for (u32 k = 0; k < len; ++k) {
       h ^= vbyte(image, pages, off + k);
       h *= 0x100000001b3ull;
     }
     out[i] = evql_mix64(h);
+  }
+}
+
+// ---- STRING_PLAIN value boundaries (see aot_kernels.h) --------------------------------
+typedef unsigned short u16;
+
+// stages chunk c (+16 look-ahead bytes, zeros behind the stream) in LDS
+__device__ __forceinline__ void str_stage_chunk(const StrScanArgs& a, u64 c, u8* bytes, u32 nthreads) {
+  const u64 base = c * kStrChunk;
+  for (u32 t = threadIdx.x; t < kStrChunk / 16 + 1; t += nthreads) {
+    const u64 p0 = base + (u64) t * 16;
+    evql_u32x4 q = {0, 0, 0, 0};
+    if (p0 < a.nbytes) {
+      q = *reinterpret_cast<const evql_u32x4*>(a.image + a.pages[p0 >> 19] + (p0 & 0x7ffffull));
+    }
+    *reinterpret_cast<evql_u32x4*>(bytes + t * 16) = q;
+  }
+}
+
+// next(p) of a value assumed to start at chunk offset p, clamped to 0xffff (= too far
+// for a table entry).  Three header bytes decide: a longer header means >= 2^21 bytes
+__device__ __forceinline__ u32 str_next(const u8* bytes, u32 p) {
+  const u32 b0 = bytes[p];
+  u32 len = b0 & 0x7f, hdr = 1;
+  if (b0 & 0x80) {
+    const u32 b1 = bytes[p + 1];
+    len |= (b1 & 0x7f) << 7;
+    hdr = 2;
+    if (b1 & 0x80) {
+      const u32 b2 = bytes[p + 2];
+      len |= (b2 & 0x7f) << 14;
+      hdr = 3;
+      if (b2 & 0x80) len = 0xffffff;
+    }
+  }
+  const u32 nxt = p + hdr + len;
+  return nxt < 0xffffu ? nxt : 0xffffu;
+}
+
+__global__ void __launch_bounds__(kBlock) k_str_chunk_tables(StrScanArgs a) {
+  __shared__ __attribute__((aligned(16))) u8 bytes[kStrChunk + 16];
+  __shared__ u16 J[2][kStrChunk];
+  __shared__ u16 H[2][kStrChunk];
+  for (u64 c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
+    str_stage_chunk(a, c, bytes, kBlock);
+    __syncthreads();
+#pragma unroll 4
+    for (u32 k = 0; k < kStrChunk / kBlock; ++k) {
+      const u32 p = threadIdx.x + k * kBlock;
+      J[0][p] = (u16) str_next(bytes, p);
+      H[0][p] = 1;
+    }
+    __syncthreads();
+    int cur = 0;
+    // pointer doubling: after round r, J = position after 2^r values or the first
+    // position at/behind the chunk's end; H = values started inside the chunk
+    for (int round = 0; round < 12; ++round) {
+      int any = 0;
+#pragma unroll 4
+      for (u32 k = 0; k < kStrChunk / kBlock; ++k) {
+        const u32 p = threadIdx.x + k * kBlock;
+        u32 j = J[cur][p], h = H[cur][p];
+        if (j < kStrChunk) {
+          h += H[cur][j];
+          j = J[cur][j];
+          any |= j < kStrChunk;
+        }
+        J[cur ^ 1][p] = (u16) j;
+        H[cur ^ 1][p] = (u16) h;
+      }
+      cur ^= 1;
+      if (!__syncthreads_or(any)) break;
+    }
+    for (u32 e = threadIdx.x; e < kStrEntries; e += kBlock) {
+      const u32 j = J[cur][e];
+      a.exits[c * kStrEntries + e] = j == 0xffffu ? (u16) kStrNone : (u16) (j - kStrChunk);
+      a.hops[c * kStrEntries + e] = H[cur][e];
+    }
+    __syncthreads();
+  }
+}
+
+// group g = kStrGroup consecutive chunks: the chunk tables composed for every entry
+__global__ void __launch_bounds__(kStrEntries) k_str_group_compose(StrScanArgs a) {
+  const u64 g = blockIdx.x;
+  const u64 c0 = g * kStrGroup;
+  const u64 nc = a.nchunks - c0 < kStrGroup ? a.nchunks - c0 : kStrGroup;
+  u64 pos = threadIdx.x;  // relative to the group's first byte
+  u32 cnt = 0;
+  bool over = false;
+  for (u64 j = 0; j < nc; ++j) {
+    const u64 cb = j * kStrChunk;
+    if (pos >= cb + kStrChunk) continue;  // a long value covers this chunk entirely
+    const u64 rel = pos - cb;
+    if (rel >= kStrEntries) {
+      over = true;
+      break;
+    }
+    const u32 x = a.exits[(c0 + j) * kStrEntries + rel];
+    if (x == kStrNone) {
+      over = true;
+      break;
+    }
+    cnt += a.hops[(c0 + j) * kStrEntries + rel];
+    pos = cb + kStrChunk + x;
+  }
+  a.gexit[g * kStrEntries + threadIdx.x] = over ? 0xffffffffu : (u32) (pos - nc * kStrChunk);
+  a.ghops[g * kStrEntries + threadIdx.x] = cnt;
+}
+
+// the true entry of every group: one short dependent chain
+__global__ void k_str_chain(StrScanArgs a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const u64 ngroups = (a.nchunks + kStrGroup - 1) / kStrGroup;
+  u64 pos = 0, vals = 0;
+  for (u64 g = 0; g < ngroups; ++g) {
+    const u64 gb = g * kStrGroup * (u64) kStrChunk;
+    const u64 nc = a.nchunks - g * kStrGroup < kStrGroup ? a.nchunks - g * kStrGroup : kStrGroup;
+    const u64 ge = gb + nc * kStrChunk;
+    if (vals >= a.nvalues) {  // everything behind the last value is padding
+      a.gentry[g] = ~0ull;
+      a.gbase[g] = vals;
+      continue;
+    }
+    a.gentry[g] = pos;
+    a.gbase[g] = vals;
+    if (pos >= ge) continue;
+    const u64 rel = pos - gb;
+    if (rel >= kStrEntries) {
+      atomicOr(&a.status[0], 1u);
+      return;
+    }
+    const u32 x = a.gexit[g * kStrEntries + rel];
+    if (x == 0xffffffffu) {
+      atomicOr(&a.status[0], 1u);
+      return;
+    }
+    vals += a.ghops[g * kStrEntries + rel];
+    pos = ge + x;
+  }
+  *reinterpret_cast<u64*>(a.status + 2) = vals;
+}
+
+// entry offset and first value index of every chunk, one thread per group
+__global__ void __launch_bounds__(kBlock) k_str_chunk_entries(StrScanArgs a) {
+  const u64 ngroups = (a.nchunks + kStrGroup - 1) / kStrGroup;
+  const u64 g = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  const u64 c0 = g * kStrGroup;
+  const u64 nc = a.nchunks - c0 < kStrGroup ? a.nchunks - c0 : kStrGroup;
+  u64 pos = a.gentry[g], vals = a.gbase[g];
+  for (u64 j = 0; j < nc; ++j) {
+    const u64 c = c0 + j;
+    const u64 cb = c * kStrChunk;
+    a.cbase[c] = vals;
+    if (pos == ~0ull || pos >= cb + kStrChunk || vals >= a.nvalues) {
+      a.centry[c] = (u16) kStrNone;
+      continue;
+    }
+    const u64 rel = pos - cb;
+    a.centry[c] = (u16) rel;
+    if (rel >= kStrEntries) {  // (the group table was OVER for this entry: not reached)
+      atomicOr(&a.status[0], 1u);
+      return;
+    }
+    const u32 x = a.exits[c * kStrEntries + rel];
+    if (x == kStrNone) {
+      atomicOr(&a.status[0], 1u);
+      return;
+    }
+    vals += a.hops[c * kStrEntries + rel];
+    pos = cb + kStrChunk + x;
+  }
+}
+
+// marks the value starts of a chunk from its true entry and emits (len << 40 | pos)
+__global__ void __launch_bounds__(1024) k_str_emit(StrScanArgs a) {
+  constexpr u32 kLevels = 12;
+  __shared__ __attribute__((aligned(16))) u8 bytes[kStrChunk + 16];
+  __shared__ u16 L[kLevels][kStrChunk];
+  __shared__ u32 markw[kStrChunk / 32];
+  __shared__ u32 wpre[kStrChunk / 32];
+  for (u64 c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
+    const u32 entry = a.centry[c];
+    const u64 base = a.cbase[c];
+    if (entry == kStrNone || base >= a.nvalues) continue;  // (uniform per workgroup)
+    str_stage_chunk(a, c, bytes, 1024);
+    if (threadIdx.x < kStrChunk / 32) markw[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < kStrChunk / 1024; ++k) {
+      const u32 p = threadIdx.x + k * 1024;
+      L[0][p] = (u16) str_next(bytes, p);
+    }
+    __syncthreads();
+    u32 nlev = 1;
+    for (u32 lv = 1; lv < kLevels; ++lv) {
+      int any = 0;
+#pragma unroll
+      for (u32 k = 0; k < kStrChunk / 1024; ++k) {
+        const u32 p = threadIdx.x + k * 1024;
+        u32 j = L[lv - 1][p];
+        if (j < kStrChunk) {
+          j = L[lv - 1][j];
+          any |= j < kStrChunk;
+        }
+        L[lv][p] = (u16) j;
+      }
+      nlev = lv + 1;
+      if (!__syncthreads_or(any)) break;
+    }
+    if (threadIdx.x == 0) markw[entry >> 5] = 1u << (entry & 31);
+    __syncthreads();
+    // reachability doubling, top level first: after level k every position at a
+    // multiple of 2^k values from the entry is marked (bits set meanwhile only add
+    // further positions of the same path)
+    for (int lv = (int) nlev - 1; lv >= 0; --lv) {
+#pragma unroll
+      for (u32 k = 0; k < kStrChunk / 1024; ++k) {
+        const u32 p = threadIdx.x + k * 1024;
+        if ((markw[p >> 5] >> (p & 31)) & 1) {
+          const u32 j = L[lv][p];
+          if (j < kStrChunk) atomicOr(&markw[j >> 5], 1u << (j & 31));
+        }
+      }
+      __syncthreads();
+    }
+    // ranks: exclusive prefix of the word popcounts (128 words: two waves)
+    if (threadIdx.x < kStrChunk / 32) {
+      const u32 v = __popc(markw[threadIdx.x]);
+      u32 incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(incl, d, 64);
+        if ((int) (threadIdx.x & 63) >= d) incl += t;
+      }
+      wpre[threadIdx.x] = incl - v;
+    }
+    __syncthreads();
+    const u32 first_wave_total = wpre[63] + __popc(markw[63]);
+#pragma unroll
+    for (u32 k = 0; k < kStrChunk / 1024; ++k) {
+      const u32 p = threadIdx.x + k * 1024;
+      const u32 w = markw[p >> 5];
+      if (!((w >> (p & 31)) & 1)) continue;
+      const u32 rank = wpre[p >> 5] + ((p >> 5) >= 64 ? first_wave_total : 0) +
+                       __popc(w & ((1u << (p & 31)) - 1u));
+      const u64 idx = base + rank;
+      if (idx >= a.nvalues) continue;
+      // the full header (a length is a u32: at most 5 bytes)
+      u64 len = 0;
+      u32 hdr = 0;
+      bool bad = true;
+      for (u32 i = 0; i < 5; ++i) {
+        const u32 b = bytes[p + i];
+        len |= (u64) (b & 0x7f) << (7 * i);
+        hdr = i + 1;
+        if (!(b & 0x80)) {
+          bad = false;
+          break;
+        }
+      }
+      const u64 pos = c * kStrChunk + p + hdr;
+      if (bad || pos + len > a.nbytes || (len >> 24) || (pos >> 40)) {
+        atomicOr(&a.status[0], 2u);
+        len = 0;
+      }
+      a.strval[idx] = (len << 40) | (pos & 0xffffffffffull);
+    }
+    __syncthreads();
+  }
+}
+
+// fallback for streams whose values outrun the tables (strings of a kilobyte and
+// more at chunk borders): one thread walks the stream and writes the chunk entries
+__global__ void k_str_walk_serial(StrScanArgs a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  u64 pos = 0, v = 0, filled = 0;
+  while (v < a.nvalues && pos < a.nbytes) {
+    const u64 c = pos / kStrChunk;
+    for (; filled < c; ++filled) {
+      a.centry[filled] = (u16) kStrNone;
+      a.cbase[filled] = v;
+    }
+    if (c >= filled) {
+      a.centry[c] = (u16) (pos - c * kStrChunk);
+      a.cbase[c] = v;
+      filled = c + 1;
+    }
+    u64 len = 0;
+    u32 hdr = 0;
+    bool bad = true;
+    for (u32 i = 0; i < 5 && pos + i < a.nbytes; ++i) {
+      const u32 b = vbyte(a.image, (const u64*) a.pages, pos + i);
+      len |= (u64) (b & 0x7f) << (7 * i);
+      hdr = i + 1;
+      if (!(b & 0x80)) {
+        bad = false;
+        break;
+      }
+    }
+    if (bad) {
+      atomicOr(&a.status[0], 2u);
+      break;
+    }
+    pos += hdr + len;
+    ++v;
+  }
+  for (; filled < a.nchunks; ++filled) {
+    a.centry[filled] = (u16) kStrNone;
+    a.cbase[filled] = v;
+  }
+  *reinterpret_cast<u64*>(a.status + 2) = v;
+}
+
+__global__ void k_copy_strings(const u8* image, const u64* pages, const u64* strpos_list,
+                               const u64* out_offsets, u64 n, u8* out) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 sp = strpos_list[i];
+    const u64 off = sp & 0xffffffffffull;
+    const u32 len = (u32) (sp >> 40);
+    u8* dst = out + out_offsets[i];
+    for (u32 k = 0; k < len; ++k) dst[k] = vbyte(image, pages, off + k);
   }
 }
 
@@ -874,11 +1199,59 @@ hipError_t launch_leb128_decode(const uint8_t* image, const uint64_t* pages, uin
 }
 
 hipError_t launch_string_hash(const uint8_t* image, const uint64_t* pages,
-                              const uint64_t* offsets, const uint32_t* lens, uint64_t n,
-                              uint64_t* out, hipStream_t s) {
+                              const uint64_t* strpos, uint64_t n, uint64_t* out, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_string_hash, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
-                     (const u64*) pages, (const u64*) offsets, lens, (u64) n, (u64*) out);
+                     (const u64*) pages, (const u64*) strpos, (u64) n, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_str_chunk_tables(const StrScanArgs& a, hipStream_t s) {
+  if (a.nchunks == 0) return hipSuccess;
+  const unsigned grid = (unsigned) (a.nchunks < 2048 ? a.nchunks : 2048);
+  hipLaunchKernelGGL(k_str_chunk_tables, dim3(grid), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_str_group_compose(const StrScanArgs& a, hipStream_t s) {
+  const u64 ngroups = (a.nchunks + kStrGroup - 1) / kStrGroup;
+  if (ngroups == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_str_group_compose, dim3((unsigned) ngroups), dim3(kStrEntries), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_str_chain(const StrScanArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_str_chain, dim3(1), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_str_chunk_entries(const StrScanArgs& a, hipStream_t s) {
+  const u64 ngroups = (a.nchunks + kStrGroup - 1) / kStrGroup;
+  if (ngroups == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_str_chunk_entries, dim3((unsigned) ((ngroups + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_str_emit(const StrScanArgs& a, hipStream_t s) {
+  if (a.nchunks == 0) return hipSuccess;
+  const unsigned grid = (unsigned) (a.nchunks < 1024 ? a.nchunks : 1024);
+  hipLaunchKernelGGL(k_str_emit, dim3(grid), dim3(1024), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_str_walk_serial(const StrScanArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_str_walk_serial, dim3(1), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_strings(const uint8_t* image, const uint64_t* pages,
+                               const uint64_t* strpos_list, const uint64_t* out_offsets,
+                               uint64_t n, uint8_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_copy_strings, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (const u64*) strpos_list, (const u64*) out_offsets,
+                     (u64) n, out);
   return hipGetLastError();
 }
 

@@ -211,7 +211,7 @@ Status table_from_image(evql_ctx* ctx, const void* image, size_t len, bool keep_
   HIP_TRY(hipMemsetAsync(t->d_image + len, 0, slack, ctx->stream));
   HIP_TRY(hipMemcpyAsync(t->d_image, image, len, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (keep_host) t->host_image.swap(tmp);
+  (void) keep_host;  // nothing of the file is kept on the host
   Status st = upload_page_tables(t.get());
   if (!st.ok()) return st;
   *out = t.release();
@@ -266,80 +266,69 @@ static uint64_t padded_rows(uint64_t n) {
   return (n + pad - 1) / pad * pad + pad;
 }
 
-// host-side sequential walk of a STRING_PLAIN column (length prefixes make the
-// stream inherently sequential, page_reader_lenencstring.cc:37-62): positions,
-// lengths and null tags of every row
-static Status scan_string_column(const evql_table* t, const ColumnLayout& c,
-                                 MaterializedColumn* m) {
-  if (t->host_image.empty()) {
-    return Status::error(EVQL_ENOTSUP, "string column without a host image");
-  }
-  const uint8_t* img = t->host_image.data();
-  const uint64_t n = t->layout.num_rows;
-  m->str_off.resize(n);
-  m->str_len.resize(n);
-  m->str_tag.resize(n);
-  // definition levels
-  std::vector<uint8_t> defined(n, 1);
-  if (c.dlevel_max > 0) {
-    uint32_t maxv = 0;
-    if (!c.dlevel_pages.empty()) memcpy(&maxv, img + c.dlevel_pages[0].offset, 4);
-    const uint32_t b = bitpack_width(maxv);
-    uint32_t buf[128];
-    uint64_t row = 0;
-    for (size_t pi = 0; pi < c.dlevel_pages.size() && row < n; ++pi) {
-      const PageRef& p = c.dlevel_pages[pi];
-      uint64_t pos = pi == 0 ? 4 : 0;
-      for (; pos + 16 * b <= p.size && row < n; pos += 16 * b) {
-        simd_unpack128(img + p.offset + pos, b, buf);
-        for (int k = 0; k < 128 && row < n; ++k, ++row) defined[row] = buf[k] == c.dlevel_max;
-      }
-    }
-    if (b == 0) std::fill(defined.begin(), defined.end(), uint8_t(c.dlevel_max == 0));
-  }
-  // virtual byte stream over the 512 KiB data pages
-  const uint64_t nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
-  auto byte_at = [&](uint64_t pos) -> uint8_t {
-    return img[c.data_pages[pos >> 19].offset + (pos & 0x7ffff)];
-  };
-  uint64_t pos = 0;
-  for (uint64_t r = 0; r < n; ++r) {
-    if (!defined[r]) {
-      m->str_off[r] = 0;
-      m->str_len[r] = 0;
-      m->str_tag[r] = EVQL_STAG_NULL;
-      continue;
-    }
-    uint64_t len = 0;
-    for (int i = 0; i < 10; ++i) {
-      if (pos >= nbytes) return Status::error(EVQL_EIO, "end of column reached");
-      uint8_t b = byte_at(pos++);
-      len |= uint64_t(b & 0x7f) << (7 * i);
-      if (!(b & 0x80)) break;
-    }
-    if (pos + len > nbytes) return Status::error(EVQL_EIO, "end of column reached");
-    m->str_off[r] = pos;
-    m->str_len[r] = uint32_t(len);
-    m->str_tag[r] = 0;
-    pos += len;
-  }
-  return Status();
-}
+static Status stream_bits(evql_table* t, const std::vector<PageRef>& pages, uint32_t* bits);
 
-// per-row (len << 40 | position) of a string column, for bytewise compares in
-// the fused kernel (evql_col_str)
-static Status upload_string_positions(evql_table* t, MaterializedColumn* m) {
-  if (m->d_strpos) return Status();
-  const uint64_t n = t->layout.num_rows;
-  std::vector<uint64_t> sp(padded_rows(n), 0);
-  for (uint64_t r = 0; r < n; ++r) {
-    if (m->str_off[r] >> 40 || m->str_len[r] >> 24) {
-      return Status::error(EVQL_ENOTSUP, "string column too large for device compares");
-    }
-    sp[r] = m->str_off[r] | (uint64_t(m->str_len[r]) << 40);
+// Value boundaries of a STRING_PLAIN column, on the device (aot_kernels.h
+// "STRING_PLAIN value boundaries"): d_strval[i] = (len << 40) | position of value i's
+// first byte in the virtual byte stream over the column's 512 KiB data pages.
+static Status locate_string_values(evql_table* t, const ColumnLayout& c, int li, uint64_t nvalues,
+                                   uint64_t* d_strval) {
+  hipStream_t s = t->ctx->stream;
+  if (nvalues == 0) return Status();
+  StrScanArgs a{};
+  a.image = t->d_image;
+  a.pages = t->d_pages[li][0];
+  a.nbytes = uint64_t(c.data_pages.size()) * kPlainPageSize;
+  a.nchunks = a.nbytes / kStrChunk;
+  a.nvalues = nvalues;
+  a.strval = d_strval;
+  if (a.nchunks == 0) return Status::error(EVQL_EIO, "end of column reached: " + c.name);
+  const uint64_t ngroups = (a.nchunks + kStrGroup - 1) / kStrGroup;
+  DevBuf<uint16_t> d_exits, d_hops, d_centry;
+  DevBuf<uint32_t> d_gexit, d_ghops, d_status;
+  DevBuf<uint64_t> d_gentry, d_gbase, d_cbase;
+  HIP_TRY(d_exits.alloc(a.nchunks * kStrEntries * 2));
+  HIP_TRY(d_hops.alloc(a.nchunks * kStrEntries * 2));
+  HIP_TRY(d_gexit.alloc(ngroups * kStrEntries * 4));
+  HIP_TRY(d_ghops.alloc(ngroups * kStrEntries * 4));
+  HIP_TRY(d_gentry.alloc(ngroups * 8));
+  HIP_TRY(d_gbase.alloc(ngroups * 8));
+  HIP_TRY(d_centry.alloc(a.nchunks * 2));
+  HIP_TRY(d_cbase.alloc(a.nchunks * 8));
+  HIP_TRY(d_status.alloc(16));
+  HIP_TRY(hipMemsetAsync(d_status, 0, 16, s));
+  a.exits = d_exits;
+  a.hops = d_hops;
+  a.gexit = d_gexit;
+  a.ghops = d_ghops;
+  a.gentry = d_gentry;
+  a.gbase = d_gbase;
+  a.centry = d_centry;
+  a.cbase = d_cbase;
+  a.status = d_status;
+  HIP_TRY(launch_str_chunk_tables(a, s));
+  HIP_TRY(launch_str_group_compose(a, s));
+  HIP_TRY(launch_str_chain(a, s));
+  HIP_TRY(launch_str_chunk_entries(a, s));
+  uint32_t status[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (status[0] & 1u) {
+    // a value outran the chunk tables: locate the chunk entries with the serial walk
+    HIP_TRY(hipMemsetAsync(d_status, 0, 16, s));
+    HIP_TRY(launch_str_walk_serial(a, s));
+    HIP_TRY(hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
   }
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_strpos), sp.size() * 8));
-  HIP_TRY(hipMemcpy(m->d_strpos, sp.data(), sp.size() * 8, hipMemcpyHostToDevice));
+  uint64_t found;
+  memcpy(&found, &status[2], 8);
+  if ((status[0] & 2u) || found < nvalues) {
+    return Status::error(EVQL_EIO, "end of column reached: " + c.name);
+  }
+  HIP_TRY(launch_str_emit(a, s));
+  HIP_TRY(hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (status[0] & 2u) return Status::error(EVQL_EIO, "end of column reached: " + c.name);
   return Status();
 }
 
@@ -365,10 +354,7 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
   evql_ctx* ctx = t->ctx;
   const ColumnLayout& c = t->layout.columns[ca.layout_index];
   (void) bits_out;
-  if (t->materialized.count(c.name)) {
-    if (ca.string_bytes) return upload_string_positions(t, &t->materialized[c.name]);
-    return Status();
-  }
+  if (t->materialized.count(c.name)) return Status();
   MaterializedColumn m;
   const uint64_t n = t->layout.num_rows;
   const uint64_t np = padded_rows(n);
@@ -378,24 +364,44 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
   const int li = ca.layout_index;
 
   if (c.logical_type == ColumnType::STRING) {
-    Status st = scan_string_column(t, c, &m);
-    if (!st.ok()) return st;
+    // per row: tag, (len << 40 | position) and a 64-bit hash of the bytes -- all
+    // computed on the device from the pages in HBM (no host copy of the file)
     m.string_hash = true;
-    DevBuf<uint64_t> d_off;
-    DevBuf<uint32_t> d_len;
-    HIP_TRY(d_off.alloc(n * 8));
-    HIP_TRY(d_len.alloc(n * 4));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_tags), np));
     HIP_TRY(hipMemsetAsync(m.d_tags, 0, np, s));
-    if (n) {
-      HIP_TRY(hipMemcpyAsync(d_off, m.str_off.data(), n * 8, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(d_len, m.str_len.data(), n * 4, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(m.d_tags, m.str_tag.data(), n, hipMemcpyHostToDevice, s));
-      HIP_TRY(launch_string_hash(t->d_image, t->d_pages[li][0], d_off, d_len, n, m.d_values, s));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_strpos), np * 8));
+    HIP_TRY(hipMemsetAsync(m.d_strpos, 0, np * 8, s));
+    uint64_t nvalues = n;
+    DevBuf<uint64_t> d_tiles;
+    const uint64_t ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+    if (c.dlevel_max > 0) {
+      HIP_TRY(hipMemsetAsync(m.d_tags, 1, np, s));
+      HIP_TRY(d_tiles.alloc((ntiles + 1) * 8));
+      uint32_t dbits = 0;
+      Status st = stream_bits(t, c.dlevel_pages, &dbits);
+      if (!st.ok()) return st;
+      HIP_TRY(launch_dlevel_tags(t->d_image, t->d_pages[li][2], dbits, c.dlevel_max, n, m.d_tags,
+                                 d_tiles, s));
+      uint64_t* d_total = d_tiles.p + ntiles;
+      HIP_TRY(launch_exclusive_scan(d_tiles, ntiles, d_total, s));
+      HIP_TRY(hipMemcpyAsync(&nvalues, d_total, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      DevBuf<uint64_t> d_strval;
+      HIP_TRY(d_strval.alloc(nvalues * 8));
+      Status st2 = locate_string_values(t, c, li, nvalues, d_strval);
+      if (!st2.ok()) return st2;
+      RtColumn src{};
+      src.mode = ColAccess::SOA;
+      src.soa = d_strval;
+      HIP_TRY(launch_expand_nullable(t->d_image, src, m.d_tags, d_tiles, n, m.d_strpos, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    } else {
+      Status st2 = locate_string_values(t, c, li, n, m.d_strpos);
+      if (!st2.ok()) return st2;
     }
+    HIP_TRY(launch_string_hash(t->d_image, t->d_pages[li][0], m.d_strpos, n, m.d_values, s));
     HIP_TRY(hipStreamSynchronize(s));
     t->materialized[c.name] = std::move(m);
-    if (ca.string_bytes) return upload_string_positions(t, &t->materialized[c.name]);
     return Status();
   }
 
@@ -1429,7 +1435,8 @@ static Status fetch_results(evql_query* q) {
         rc[c].soa = q->nested_flat[c];
       } else if (ca.mode == ColAccess::SOA) {
         const MaterializedColumn& m = t->materialized[ca.name];
-        rc[c].soa = m.d_values;
+        // strings: (len << 40 | position); their bytes are copied out below
+        rc[c].soa = ca.string_hash ? m.d_strpos : m.d_values;
         rc[c].tags = m.d_tags;
       }
     }
@@ -1448,6 +1455,34 @@ static Status fetch_results(evql_query* q) {
     HIP_TRY(hipMemcpyAsync(q->first_vals.data(), d_vals, n * nc * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(q->first_tags.data(), d_tags, n * nc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // bytes of the first-row strings: one packed heap per string column
+    q->first_str_off.assign(n * nc, 0);
+    q->first_str_heap.clear();
+    for (uint32_t c = 0; c < nc; ++c) {
+      const ColAccess& ca = kp.cols[c];
+      if (!ca.string_hash) continue;
+      std::vector<uint64_t> offs(n);
+      uint64_t total = q->first_str_heap.size();
+      const uint64_t heap0 = total;
+      for (uint64_t i = 0; i < n; ++i) {
+        offs[i] = total - heap0;
+        q->first_str_off[uint64_t(c) * n + i] = total;
+        if (!q->first_tags[uint64_t(c) * n + i]) total += q->first_vals[uint64_t(c) * n + i] >> 40;
+      }
+      const uint64_t bytes = total - heap0;
+      q->first_str_heap.resize(total);
+      if (bytes == 0) continue;
+      DevBuf<uint64_t> d_offs;
+      DevBuf<uint8_t> d_heap;
+      HIP_TRY(d_offs.alloc(n * 8));
+      HIP_TRY(d_heap.alloc(bytes));
+      HIP_TRY(hipMemcpyAsync(d_offs, offs.data(), n * 8, hipMemcpyHostToDevice, s));
+      // (NULL rows carry strpos 0: length 0, nothing copied)
+      HIP_TRY(launch_copy_strings(t->d_image, t->d_pages[ca.layout_index][0], d_vals.p + uint64_t(c) * n,
+                                  d_offs, n, d_heap, s));
+      HIP_TRY(hipMemcpyAsync(q->first_str_heap.data() + heap0, d_heap, bytes, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
   }
   q->stats.num_groups = total_groups;
   q->emit_pos = 0;
@@ -1695,7 +1730,6 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
     if (!st.ok()) return st;
   }
   const KernelPlan& kp = q->kp;
-  evql_table* t = q->table;
   const size_t nsel = q->select.size();
   const bool partial = q->group_mode == EVQL_MODE_PARTIAL;
   q->out_cols.assign(partial ? 2 : nsel, std::vector<uint8_t>());
@@ -1712,7 +1746,6 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
     const uint64_t* st = rec + 1 + kp.state_word_base();
     bool have_inputs = false;
     if (kp.need_first_row) {
-      const uint64_t row = rec[1 + kp.first_row_word()];
       for (uint32_t c = 0; c < nc; ++c) {
         const ColAccess& ca = kp.cols[c];
         Value v;
@@ -1720,15 +1753,10 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
         v.tag = q->first_tags[uint64_t(c) * q->ngroups + g];
         const uint64_t raw = q->first_vals[uint64_t(c) * q->ngroups + g];
         if (ca.string_hash) {
-          const MaterializedColumn& m = t->materialized[ca.name];
-          v.tag = m.str_tag[row];
           if (!v.tag) {
-            const ColumnLayout& cl = t->layout.columns[ca.layout_index];
-            v.str.resize(m.str_len[row]);
-            for (uint32_t k = 0; k < m.str_len[row]; ++k) {
-              const uint64_t pos = m.str_off[row] + k;
-              v.str[k] = char(t->host_image[cl.data_pages[pos >> 19].offset + (pos & 0x7ffff)]);
-            }
+            const uint64_t off = q->first_str_off[uint64_t(c) * q->ngroups + g];
+            v.str.assign(reinterpret_cast<const char*>(q->first_str_heap.data()) + off,
+                         size_t(raw >> 40));
           }
         } else if (ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float) {
           double d = double(raw);
@@ -1820,7 +1848,6 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
 // loop above computes them; ORDER BY evaluates its sort expressions over these
 static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* outs) {
   const KernelPlan& kp = q->kp;
-  evql_table* t = q->table;
   const size_t nsel = q->select.size();
   const size_t rw = size_t(kp.words_per_slot()) + 1;
   const uint32_t nc = uint32_t(kp.cols.size());
@@ -1830,7 +1857,6 @@ static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* ou
   std::vector<Value> scan_vals(nc), sel_inputs(q->scan_select.size());
   bool have_inputs = false;
   if (kp.need_first_row) {
-    const uint64_t row = rec[1 + kp.first_row_word()];
     for (uint32_t c = 0; c < nc; ++c) {
       const ColAccess& ca = kp.cols[c];
       Value v;
@@ -1838,15 +1864,10 @@ static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* ou
       v.tag = q->first_tags[uint64_t(c) * q->ngroups + g];
       const uint64_t raw = q->first_vals[uint64_t(c) * q->ngroups + g];
       if (ca.string_hash) {
-        const MaterializedColumn& m = t->materialized[ca.name];
-        v.tag = m.str_tag[row];
         if (!v.tag) {
-          const ColumnLayout& cl = t->layout.columns[ca.layout_index];
-          v.str.resize(m.str_len[row]);
-          for (uint32_t k = 0; k < m.str_len[row]; ++k) {
-            const uint64_t pos = m.str_off[row] + k;
-            v.str[k] = char(t->host_image[cl.data_pages[pos >> 19].offset + (pos & 0x7ffff)]);
-          }
+          const uint64_t off = q->first_str_off[uint64_t(c) * q->ngroups + g];
+          v.str.assign(reinterpret_cast<const char*>(q->first_str_heap.data()) + off,
+                       size_t(raw >> 40));
         }
       } else if (ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float) {
         double d = double(raw);

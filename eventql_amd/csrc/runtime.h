@@ -115,12 +115,9 @@ struct MaterializedColumn {
   uint64_t* d_values = nullptr;
   uint8_t* d_tags = nullptr;
   bool string_hash = false;
-  // strings compared on the device: (len << 40) | byte position, per row
+  // strings: (len << 40) | byte position of the value in the column's page stream,
+  // per row (bytewise compares in the fused kernel, result emission)
   uint64_t* d_strpos = nullptr;
-  // strings: host-side positions for result emission
-  std::vector<uint64_t> str_off;
-  std::vector<uint32_t> str_len;
-  std::vector<uint8_t> str_tag;
 
   MaterializedColumn() = default;
   MaterializedColumn(const MaterializedColumn&) = delete;
@@ -131,9 +128,6 @@ struct MaterializedColumn {
     std::swap(d_tags, o.d_tags);
     std::swap(d_strpos, o.d_strpos);
     std::swap(string_hash, o.string_hash);
-    str_off.swap(o.str_off);
-    str_len.swap(o.str_len);
-    str_tag.swap(o.str_tag);
     return *this;
   }
   ~MaterializedColumn() {
@@ -148,7 +142,6 @@ struct evql_table {
   evql::TableLayout layout;
   uint8_t* d_image = nullptr;
   uint64_t image_len = 0;
-  std::vector<uint8_t> host_image;  // kept for string emission; empty if generated
   // device page tables: [column][0 data, 1 rlevel, 2 dlevel]
   std::vector<std::vector<uint64_t*>> d_pages;
   std::vector<uint64_t> payload_bytes;
@@ -235,6 +228,8 @@ struct evql_query {
   uint64_t ngroups = 0;
   std::vector<uint64_t> first_vals;  // [col][group]
   std::vector<uint8_t> first_tags;
+  std::vector<uint8_t> first_str_heap;  // bytes of the first-row strings
+  std::vector<uint64_t> first_str_off;  // [col][group] offset into the heap
   uint64_t emit_pos = 0;
   std::vector<std::vector<uint8_t>> out_cols;
   // ORDER BY .. LIMIT fused above the GROUP BY (evql_query_set_order)
