@@ -39,6 +39,9 @@ QUERIES = {
     # config 3 over the reference's default integer encoding (k, a, b UINT64_LEB128)
     "config3l": ("k, sum(v), count(1), sum(b) WHERE a>30000 AND b<30000 GROUP BY k", "kabv", 4),
     "config4": ("u, sum(a), count(1), sum(v) GROUP BY u  (u uniform in [0,1e7))", "uav", 3),
+    # BASELINE configs[3] as written: the key is a STRING ("g" + u, STRING_PLAIN)
+    "config4s": ("s, sum(a), count(1), sum(v) GROUP BY s  (s = 'g' + u, u uniform in [0,1e7), "
+                 "STRING_PLAIN key)", None, 3),
     # nested: REPEATED RECORD items{position, price}, Dremel flattening (CSTableScan)
     "config5": ("items.position, count(1), sum(items.price) GROUP BY items.position "
                 "(REPEATED RECORD items, rlevel 1 / dlevel 2)", None, 2),
@@ -136,7 +139,8 @@ def main():
             dist.init_process_group(backend)
 
     query_text, columns, ncols = QUERIES[args.workload]
-    high_card = args.workload == "config4"
+    high_card = args.workload in ("config4", "config4s")
+    string_keys = args.workload == "config4s"
     n_keys = 10_000_000
     nested = args.workload in ("config5", "config5w")
     # config 4 = 1.25e8 rows per partition, config 5 = 1e8 records
@@ -144,7 +148,8 @@ def main():
                          (100_000_000 if nested or args.workload == "config3l" else 1_000_000_000))
     plan_fn = {"config2": B.config2, "config3": B.config3, "config3l": B.config3,
                "config5": config5_plan, "config5w": config5w_plan,
-               "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw)}[args.workload]
+               "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw),
+               "config4s": lambda **kw: B.config4s(groups_hint=n_keys, **kw)}[args.workload]
     gen_kw = dict(u_mod=n_keys) if high_card else {}
     if args.k_bits:
         gen_kw["k_bits"] = args.k_bits
@@ -170,6 +175,15 @@ def main():
         table = ctx.open_image(w.image())
         w.close()
         del c
+        ctx.synchronize()
+        t0m = time.perf_counter()
+        table.query(plan_fn()).close()
+        ctx.synchronize()
+        materialize_ms = (time.perf_counter() - t0m) * 1e3
+    elif string_keys:
+        # generated in HBM and encoded by the device writer; the first operator finds
+        # the value boundaries of the STRING_PLAIN stream and hashes the keys, once
+        table = B.string_key_table(ctx, rows, n_keys, seed)
         ctx.synchronize()
         t0m = time.perf_counter()
         table.query(plan_fn()).close()
@@ -294,7 +308,10 @@ def main():
             merge = ("rccl all_to_all of hash-partitioned group records + merge kernel"
                      if high_card else "rccl all_gather of dense group records + merge kernel")
         out = {
-            "metric": "rows/sec scanned+aggregated, 1e9-row 4-col GROUP BY",
+            # BASELINE.json's metric, quoted on config3; the other workloads say what they are
+            "metric": ("rows/sec scanned+aggregated, 1e9-row 4-col GROUP BY"
+                       if args.workload == "config3" else
+                       "rows/sec scanned+aggregated, %s (%d rows/GPU)" % (args.workload, rows)),
             "value": total_rows / dt,
             "unit": "rows/s",
             "n_gpus": world,
@@ -332,7 +349,21 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline and not leb:
-            if nested:
+            if string_keys:
+                import oracle_lib as O
+                n_s = args.cpu_sample_rows or 4_000_000
+                ts = B.string_key_table(ctx, n_s, n_keys, seed)
+                img_s = ts.download_image()
+                ts.close()
+                t0c = time.time()
+                res = O.oracle_run(img_s, plan_fn())
+                dtc = time.time() - t0c
+                out["cpu_baseline"] = dict(
+                    value=n_s / dtc, unit="rows/s", cores=1, kind="port",
+                    sample="%d-row instance of the same table/query, oracle (C restatement of "
+                           "FastCSTableScan+VM+GroupBy, SHA1-keyed map), %d groups, %.1f s"
+                           % (n_s, res.nrows, dtc))
+            elif nested:
                 import oracle_lib as O
                 n_s = min(rows, args.cpu_sample_rows or 2_000_000)
                 img_s, _ = synth.items_table_image(n_s, seed=3)
@@ -348,8 +379,10 @@ def main():
             else:
                 sample = args.cpu_sample_rows or (4_000_000 if high_card else 80_000_000)
                 out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
-        if leb:
+        if leb or string_keys:
             out["config"]["materialize_ms_first_operator"] = materialize_ms
+        if string_keys:
+            out["config"]["encodings"] = "s STRING_PLAIN (boundaries + 64-bit hashes found on the device once per table), a UINT64_PLAIN, v FLOAT_IEEE754"
         if nested:
             # the Dremel flattening (level decode, slot maps, LEB128 decode) runs when
             # the first operator over these columns is created (together with the

@@ -33,7 +33,44 @@ def config4(groups_hint=10_000_000, **kw):
                 group_by=[col("u")], groups_hint=groups_hint, **kw)
 
 
+STRING_KEY_SCHEMA = dict(s=K.T_STRING, a=K.T_UINT64, v=K.T_FLOAT64)
+STRING_KEY_COLUMNS = [
+    dict(name="s", logical_type=K.COL_STRING, storage_type=K.ENC_STRING_PLAIN),
+    dict(name="a", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+    dict(name="v", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754),
+]
+
+
+def config4s(groups_hint=10_000_000, **kw):
+    """BASELINE.json configs[3] as written: high-cardinality GROUP BY on a STRING key
+    ("g" + u, STRING_PLAIN; identity = two 64-bit hashes of the bytes), 3 aggregates"""
+    return Plan(STRING_KEY_SCHEMA, select=[col("s"), sum_(col("a")), count(1), sum_(col("v"))],
+                group_by=[col("s")], groups_hint=groups_hint, **kw)
+
+
+def string_key_table(ctx, rows, n_keys, seed):
+    """config-4 partition with a real string key, generated in HBM (torch RNG) and
+    encoded by the device writer: s = "g" + u (u uniform in [0, n_keys)), a in
+    [0, 65536), v in [0, 16384).  Returns the resident table."""
+    import torch
+    from . import synth
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed & 0x7fffffffffffffff)
+    u = torch.randint(0, n_keys, (rows,), generator=g, device="cuda", dtype=torch.int64)
+    a = torch.randint(0, 65536, (rows,), generator=g, device="cuda", dtype=torch.int64)
+    v = torch.rand(rows, generator=g, device="cuda", dtype=torch.float64) * 16384.0
+    words, heap = synth.device_string_keys(u)
+    del u
+    torch.cuda.synchronize()
+    t = ctx.table_from_device_columns(
+        STRING_KEY_COLUMNS, {"s": words.data_ptr(), "a": a.data_ptr(), "v": v.data_ptr()}, None,
+        rows, heaps={"s": heap.data_ptr()})
+    torch.cuda.synchronize()
+    return t
+
+
 def precompile_all():
     from . import compile_only
     for p in (config2(), config3(), config4()):
         compile_only(p, PLAIN_COLUMNS)
+    compile_only(config4s(), STRING_KEY_COLUMNS)

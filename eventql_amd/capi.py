@@ -135,7 +135,7 @@ class ColumnSpec(C.Structure):
 
 
 class DeviceColumn(C.Structure):
-    _fields_ = [("values", C.c_void_p), ("nulls", C.c_void_p)]
+    _fields_ = [("values", C.c_void_p), ("nulls", C.c_void_p), ("bytes", C.c_void_p)]
 
 
 class ColumnBuf(C.Structure):

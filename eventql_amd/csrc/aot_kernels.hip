@@ -1509,6 +1509,49 @@ __global__ void __launch_bounds__(kBlock) k_wr_leb_emit(u8* image, const u64* pa
   }
 }
 
+// STRING_PLAIN streams (LenencStringPageWriter, page_writer_lenencstring.cc:37-69):
+// `varuint length, bytes` per value.  A value is (len << 40 | offset into `heap`).
+__device__ __forceinline__ u32 wr_str_size(u64 sp) {
+  const u32 len = (u32) (sp >> 40);
+  return len + (len < 0x80u ? 1u : (len < 0x4000u ? 2u : (len < 0x200000u ? 3u : 4u)));
+}
+
+__global__ void __launch_bounds__(kBlock) k_wr_str_count(const u64* dense, u64 n,
+                                                         u64* chunk_bytes) {
+  const u64 i0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 len = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) len += i0 + j < n ? wr_str_size(dense[i0 + j]) : 0;
+  u32 total;
+  block_excl_scan(len, &total);
+  if (threadIdx.x == 0) chunk_bytes[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock) k_wr_str_emit(u8* image, const u64* pages,
+                                                        const u64* dense, u64 n,
+                                                        const u64* chunk_offsets, const u8* heap) {
+  const u64 i0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 len = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) len += i0 + j < n ? wr_str_size(dense[i0 + j]) : 0;
+  u32 total;
+  u64 pos = chunk_offsets[blockIdx.x] + block_excl_scan(len, &total);
+  for (int j = 0; j < 8; ++j) {
+    if (i0 + j >= n) break;
+    const u64 sp = dense[i0 + j];
+    u32 l = (u32) (sp >> 40);
+    const u8* src = heap + (sp & 0xffffffffffull);
+    u32 v = l;
+    do {
+      u8 b = v & 0x7f;
+      v >>= 7;
+      if (v) b |= 0x80;
+      *wr_stream_byte(image, pages, pos++) = b;
+    } while (v);
+    for (u32 k = 0; k < l; ++k) *wr_stream_byte(image, pages, pos++) = src[k];
+  }
+}
+
 }  // namespace
 
 hipError_t launch_wr_count_defined(const uint8_t* nulls, uint64_t nrows, uint64_t* tile_counts,
@@ -1571,6 +1614,26 @@ hipError_t launch_synth(const SynthArgs* d_args, uint64_t num_rows, hipStream_t 
   if (nchunks == 0) return hipSuccess;
   hipLaunchKernelGGL(k_synth, dim3((unsigned) ((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      s, d_args, (u64) nchunks);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_str_count(const uint64_t* dense, uint64_t n, uint64_t* chunk_bytes,
+                               hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_str_count, dim3((unsigned) ntiles), dim3(kBlock), 0, s,
+                     (const u64*) dense, (u64) n, (u64*) chunk_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_str_emit(uint8_t* image, const uint64_t* pages, const uint64_t* dense,
+                              uint64_t n, const uint64_t* chunk_offsets, const uint8_t* heap,
+                              hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_str_emit, dim3((unsigned) ntiles), dim3(kBlock), 0, s, image,
+                     (const u64*) pages, (const u64*) dense, (u64) n, (const u64*) chunk_offsets,
+                     heap);
   return hipGetLastError();
 }
 

@@ -16,6 +16,12 @@
 // (cstable_format.cc TableWriter, one whole column per `put`) produces whenever
 // each stream of an optional column fits one page, and exactly for required
 // columns of any size.  Readers follow the page index, so every order is valid.
+//
+// String columns (LenencStringPageWriter, page_writer_lenencstring.cc:37-69) arrive
+// as one word per row, (length << 40) | offset into a byte heap in HBM -- the form in
+// which the scan side names a string of a resident table (MaterializedColumn::d_strpos)
+// -- and are encoded like LEB128 streams: sizes per 2048-value chunk, scan, bytes at
+// their stream positions.
 #include <cstring>
 #include <memory>
 #include "runtime.h"
@@ -65,8 +71,12 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
     if (c.rlevel_max > 0 || c.dlevel_max > 1) {
       return Status::error(EVQL_ENOTSUP, "device writer: repeated / nested column " + c.name);
     }
-    if (c.logical_type == ColumnType::STRING || c.storage_type == ColumnEncoding::STRING_PLAIN) {
-      return Status::error(EVQL_ENOTSUP, "device writer: string column " + c.name);
+    const bool is_string = c.storage_type == ColumnEncoding::STRING_PLAIN;
+    if (is_string != (c.logical_type == ColumnType::STRING)) {
+      return Status::error(EVQL_EARG, "device writer: STRING columns use STRING_PLAIN: " + c.name);
+    }
+    if (is_string && !in[i].bytes && n) {
+      return Status::error(EVQL_EARG, "device writer: string column without a byte heap: " + c.name);
     }
     if ((c.dlevel_max > 0) != (in[i].nulls != nullptr)) {
       return Status::error(EVQL_EARG, "device writer: NULL flags are given exactly for optional "
@@ -96,11 +106,16 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
       case ColumnEncoding::BOOLEAN_BITPACKED:
         w.bits = bitpack_width(c.bitpack_max_value);
         break;
+      case ColumnEncoding::STRING_PLAIN:
       case ColumnEncoding::UINT64_LEB128: {
         const uint64_t nchunks = (w.ndef + kDecodeTile - 1) / kDecodeTile;
         HIP_TRY(w.chunk_offsets.alloc((nchunks + 2) * 8));
         if (nchunks) {
-          HIP_TRY(launch_wr_leb_count(w.dense, w.ndef, w.chunk_offsets, s));
+          if (is_string) {
+            HIP_TRY(launch_wr_str_count(w.dense, w.ndef, w.chunk_offsets, s));
+          } else {
+            HIP_TRY(launch_wr_leb_count(w.dense, w.ndef, w.chunk_offsets, s));
+          }
           HIP_TRY(launch_exclusive_scan(w.chunk_offsets, nchunks, w.chunk_offsets.p + nchunks, s));
           HIP_TRY(hipMemcpyAsync(&w.leb_bytes, w.chunk_offsets.p + nchunks, 8,
                                  hipMemcpyDeviceToHost, s));
@@ -258,6 +273,10 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
         HIP_TRY(launch_wr_bitpack(t->d_image, t->d_pages[i][0], w.dense, nullptr, w.ndef, w.bits, s));
         break;
       }
+      case ColumnEncoding::STRING_PLAIN:
+        HIP_TRY(launch_wr_str_emit(t->d_image, t->d_pages[i][0], w.dense, w.ndef, w.chunk_offsets,
+                                   in[i].bytes, s));
+        break;
       default:
         HIP_TRY(launch_wr_leb_emit(t->d_image, t->d_pages[i][0], w.dense, w.ndef, w.chunk_offsets,
                                    s));

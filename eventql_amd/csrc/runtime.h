@@ -265,6 +265,7 @@ Status upload_page_tables(evql_table* t);
 struct DeviceColumnIn {
   const uint64_t* values;  // device, num_rows value words
   const uint8_t* nulls;    // device, num_rows bytes (1 = NULL) or nullptr
+  const uint8_t* bytes;    // device, string columns: the heap `values` point into
 };
 Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& specs,
                                  const std::vector<DeviceColumnIn>& in, uint64_t num_rows,

@@ -142,3 +142,33 @@ def table_columns(n, seed=SEED, k_mod=1000):
     b = (x >> np.uint64(24)) & np.uint64(0xFFFF)
     v = (x >> np.uint64(40)).astype(np.float64) / 1024.0
     return dict(x=x, k=k, a=a, b=b, v=v)
+
+
+def device_string_keys(u, prefix=b"g"):
+    """strings prefix + decimal(u[i]) for a torch int64 tensor `u` on the GPU, in the
+    form evql_table_from_device_columns takes for a STRING_PLAIN column: (words, heap)
+    with words[i] = (len << 40) | offset into the uint8 heap.  Input generation for the
+    benchmark / tests (torch is plumbing here); SURVEY.md 8c(ii): s = "g" + k."""
+    import torch
+    n = u.numel()
+    p = len(prefix)
+    ndig = torch.ones_like(u)
+    lim = 10
+    for _ in range(18):
+        ndig += (u >= lim).to(torch.int64)
+        lim *= 10
+    lens = ndig + p
+    offs = torch.cumsum(lens, 0) - lens
+    total = int((offs[-1] + lens[-1]).item()) if n else 0
+    heap = torch.zeros(max(total, 1), dtype=torch.uint8, device=u.device)
+    for j, ch in enumerate(prefix):
+        heap[offs + j] = ch
+    maxd = int(ndig.max().item()) if n else 0
+    for d in range(maxd):
+        # digit d counted from the most significant one, for the rows that have it
+        sel = ndig > d
+        us, nd, of = u[sel], ndig[sel], offs[sel]
+        digit = torch.div(us, torch.pow(10, nd - 1 - d), rounding_mode="floor") % 10
+        heap[of + p + d] = (digit + 48).to(torch.uint8)
+    words = (lens << 40) | offs
+    return words, heap

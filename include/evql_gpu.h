@@ -327,13 +327,17 @@ typedef struct {
                            * / bool as 0|1); entries of NULL rows are ignored */
   const uint8_t* nulls;   /* DEVICE pointer: num_rows bytes, 1 = NULL; given
                            * exactly for optional columns (dlevel_max == 1) */
+  const uint8_t* bytes;   /* DEVICE pointer, STRING_PLAIN columns only: the byte heap;
+                           * values[i] = (length << 40) | offset of string i in it
+                           * (length < 2^24, offset < 2^40).  NULL otherwise */
 } evql_device_column_t;
 /*
  * Encodes `ncols` SoA columns that sit in HBM into a cstable v0.2.0 image, in
  * HBM, and returns it as a table (evql_table_download_image / _write_file give
  * the file).  Flat schemas: required or optional (dlevel_max 1) columns in
  * UINT64_PLAIN, FLOAT_IEEE754, UINT32_PLAIN, UINT32_BITPACKED,
- * BOOLEAN_BITPACKED or UINT64_LEB128; repeated / nested columns and strings
+ * BOOLEAN_BITPACKED, UINT64_LEB128 or STRING_PLAIN (LenencStringPageWriter,
+ * io/cstable/columns/page_writer_lenencstring.cc:37-69); repeated / nested columns
  * answer EVQL_ENOTSUP (evql_writer_* covers them on the host).  Pages are placed
  * column after column (an optional column's definition levels before its data);
  * for required columns the file is byte-identical to the one evql_writer_*
