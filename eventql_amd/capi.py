@@ -156,6 +156,7 @@ class QueryStats(C.Structure):
         ("total_ms", C.c_double),
         ("n_kernel_launches", C.c_uint32),
         ("used_lds_table", C.c_uint32),
+        ("estimated_groups", C.c_uint64),
     ]
 
 

@@ -706,12 +706,6 @@ int evql_compile_only(const evql_plan_desc_t* plan, const evql_column_info_t* co
     if (c.mode == ColAccess::BITPACKED) c.bits = uint32_t(columns[c.layout_index].payload_bytes);
   }
   q.source = generate_kernel_source(q.kp);
-  if (const char* dump = getenv("EVQL_DUMP_SOURCE")) {  // debugging aid
-    if (FILE* f = fopen(dump, "w")) {
-      fwrite(q.source.data(), 1, q.source.size(), f);
-      fclose(f);
-    }
-  }
   std::vector<char> code;
   st = compile_to_code_object(q.source, &code);
   if (!st.ok()) return ret(st);

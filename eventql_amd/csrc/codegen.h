@@ -76,6 +76,11 @@ struct KernelPlan {
   int tile_rows() const { return block * 2 * unroll; }
 };
 
+// launch shape for `hint` expected groups (planner.cc)
+void choose_launch_shape(KernelPlan* kp, uint64_t hint);
+uint64_t lds_table_max_slots(const KernelPlan& kp);
+bool partitioned_path_possible(const KernelPlan& kp);
+
 // the generated translation unit (device library excluded)
 std::string generate_kernel_source(const KernelPlan& kp);
 

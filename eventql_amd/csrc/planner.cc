@@ -115,6 +115,69 @@ int op_for_minmax(uint32_t fn) {
 
 }  // namespace
 
+// ---- launch shape ---------------------------------------------------------------------
+// Chooses block size, unroll, LDS table size and -- for `hint` groups far beyond
+// what an LDS table holds -- the partitioned path.  Called when the plan is built
+// (hint = evql_plan_desc_t::groups_hint) and again by the runtime when a plan
+// without a hint turns out to be high-cardinality (query_launch's sample pass).
+uint64_t lds_table_max_slots(const KernelPlan& kp) {
+  const uint64_t W = uint64_t(kp.words_per_slot());
+  uint64_t smax = 256;
+  while ((smax * 2 + 2) * 8 * W <= 150 * 1024) smax <<= 1;
+  return smax;
+}
+
+bool partitioned_path_possible(const KernelPlan& kp) {
+  // (a nullable exact key needs the NULL slot; count_distinct inserts into its pair
+  // set from the row function, which the partition passes would run twice)
+  return kp.key_mode != KEY_NONE &&
+         !(kp.key_mode == KEY_EXACT && expr_may_be_null(kp.group[0], kp.cols)) &&
+         kp.n_distinct == 0;
+}
+
+void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
+  KernelPlan& kp = *kpp;
+  kp.block = 256;
+  kp.partitioned = false;
+  // loads in flight per lane = columns x unroll; ~16 saturate HBM (measured: 2
+  // columns 2.54 ms at unroll 4, 2.43 ms at unroll 8; 4 columns spill at 8)
+  kp.unroll = kp.cols.size() <= 2 ? 8 : 4;
+  kp.lds_slots = 0;
+  if (kp.key_mode == KEY_NONE) return;
+  // One 1024-thread workgroup per CU owning (almost) the whole 160 KiB LDS: the
+  // probe loop of a wave runs as long as its slowest lane, so the table is kept
+  // sparse (load factor <= 1/4 where the LDS allows) -- measured on MI355X:
+  // 1000 groups in 4096 slots ran 2.1x faster than in 2048 slots.
+  const uint64_t smax = lds_table_max_slots(kp);
+  // Dense keys are placed by identity, so even `hint` close to the slot count
+  // works (4000 dense groups in 4096 slots: 0.63 ms vs 24 ms HBM-only for 2e8
+  // rows); a workgroup whose table does thrash switches itself to the HBM
+  // table (`bypass`).  Only far beyond the LDS capacity is the table skipped.
+  if (hint > 8 * smax && partitioned_path_possible(kp)) {
+    // high cardinality: one random HBM atomic per state word per row tops out at
+    // the chip's scattered-atomic rate (~2e10/s measured).  Instead the passing
+    // rows are radix-partitioned into buckets small enough for the LDS table
+    // (streaming traffic) and every bucket is aggregated in LDS.
+    kp.partitioned = true;
+    kp.lds_slots = int(smax);
+    kp.block = 1024;
+    kp.part_bits = 8;
+    while (kp.part_bits < 14 && (hint >> kp.part_bits) > smax / 2) ++kp.part_bits;
+  } else if (hint > 8 * smax) {
+    kp.lds_slots = 0;  // (nullable exact key) aggregate straight into the HBM table
+    kp.block = 256;
+  } else {
+    uint64_t s = smax;
+    if (hint != 0) {
+      s = 1024;
+      while (s < hint * 4) s <<= 1;
+      if (s > smax) s = smax;
+    }
+    kp.lds_slots = int(s);
+    kp.block = 1024;
+  }
+}
+
 Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan,
                          evql_query* q, bool* unsupported) {
   *unsupported = false;
@@ -495,8 +558,9 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     }
   }
   if (int(kp.states.size()) > kMaxStateWords) return unsup("too many aggregate state words");
+  // update words that travel in a partition tuple (a count's "+1" does not)
   q->n_update_words = 0;
-  for (const auto& a : kp.aggs) q->n_update_words += a.nwords;
+  for (const auto& a : kp.aggs) q->n_update_words += a.fn == EVQL_AGG_COUNT ? 0 : a.nwords;
   // PartialGroupBy rows carry SHA1(tuple bytes): with a hashed identity the key
   // values have to be re-read from the group's first row
   if (plan->group_mode == EVQL_MODE_PARTIAL && kp.key_mode == KEY_HASHED) {
@@ -505,60 +569,7 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
 
   kp.has_row_filter = plan->row_filter_bits != nullptr;
 
-  // ---- launch shape -------------------------------------------------------------------
-  kp.block = 256;
-  // loads in flight per lane = columns x unroll; ~16 saturate HBM (measured: 2
-  // columns 2.54 ms at unroll 4, 2.43 ms at unroll 8; 4 columns spill at 8)
-  kp.unroll = kp.cols.size() <= 2 ? 8 : 4;
-  kp.lds_slots = 0;
-  if (kp.key_mode != KEY_NONE) {
-    // One 1024-thread workgroup per CU owning (almost) the whole 160 KiB LDS: the
-    // probe loop of a wave runs as long as its slowest lane, so the table is kept
-    // sparse (load factor <= 1/4 where the LDS allows) -- measured on MI355X:
-    // 1000 groups in 4096 slots ran 2.1x faster than in 2048 slots.
-    const uint64_t W = uint64_t(kp.words_per_slot());
-    uint64_t smax = 256;
-    while ((smax * 2 + 2) * 8 * W <= 150 * 1024) smax <<= 1;
-    const uint64_t hint = plan->groups_hint;
-    // Dense keys are placed by identity, so even `hint` close to the slot count
-    // works (4000 dense groups in 4096 slots: 0.63 ms vs 24 ms HBM-only for 2e8
-    // rows); a workgroup whose table does thrash switches itself to the HBM
-    // table (`bypass`).  Only far beyond the LDS capacity is the table skipped.
-    const char* fp = getenv("EVQL_FORCE_PARTITIONED");
-    // (count_distinct inserts into its pair set from the row function, which the
-    // partition passes would run twice)
-    const bool part_ok = !(kp.key_mode == KEY_EXACT && expr_may_be_null(kp.group[0], kp.cols)) &&
-                         kp.n_distinct == 0;
-    if ((hint > 8 * smax || (fp && atoi(fp) == 1)) && part_ok && !(fp && atoi(fp) == 0)) {
-      // high cardinality: one random HBM atomic per state word per row tops out at
-      // the chip's scattered-atomic rate (~2e10/s measured).  Instead the passing
-      // rows are radix-partitioned into buckets small enough for the LDS table
-      // (streaming traffic) and every bucket is aggregated in LDS.
-      kp.partitioned = true;
-      kp.lds_slots = int(smax);
-      kp.block = 1024;
-      kp.part_bits = 8;
-      while (kp.part_bits < 14 && (hint >> kp.part_bits) > smax / 2) ++kp.part_bits;
-    } else if (hint > 8 * smax) {
-      kp.lds_slots = 0;  // (nullable exact key) aggregate straight into the HBM table
-      kp.block = 256;
-    } else {
-      uint64_t s = smax;
-      if (hint != 0) {
-        s = 1024;
-        while (s < hint * 4) s <<= 1;
-        if (s > smax) s = smax;
-      }
-      kp.lds_slots = int(s);
-      kp.block = 1024;
-    }
-  }
-  // tuning overrides (experiments only)
-  if (const char* e = getenv("EVQL_FORCE_BLOCK")) kp.block = atoi(e);
-  if (const char* e = getenv("EVQL_FORCE_UNROLL")) kp.unroll = atoi(e);
-  if (const char* e = getenv("EVQL_FORCE_LDS_SLOTS")) {
-    if (kp.key_mode != KEY_NONE) kp.lds_slots = atoi(e);
-  }
+  choose_launch_shape(&kp, plan->groups_hint);
   return Status();
 }
 

@@ -2,6 +2,7 @@
 // kernel, execution and result emission.
 #include "runtime.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -974,6 +975,8 @@ static uint64_t word_identity(int op) {
   }
 }
 
+static Status compile_plan_kernels(evql_query* q);
+
 Status query_prepare(evql_query* q) {
   evql_table* t = q->table;
   evql_ctx* ctx = q->ctx;
@@ -999,8 +1002,7 @@ Status query_prepare(evql_query* q) {
       if (!st.ok()) return st;
     }
   }
-  q->source = generate_kernel_source(q->kp);
-  Status st = compile_kernel(ctx, q->source, &q->module, true);
+  Status st = compile_plan_kernels(q);
   if (!st.ok()) return st;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_status), 16));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_counters), 64));
@@ -1011,13 +1013,6 @@ Status query_prepare(evql_query* q) {
     HIP_TRY(hipMemcpy(q->d_row_filter, q->row_filter_host.data(), q->row_filter_host.size(),
                       hipMemcpyHostToDevice));
   }
-  // persistent grid: one wave of workgroups per CU slot
-  int per_cu = 1;
-  hipError_t oe = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, q->module.fn,
-                                                                     q->kp.block, 0);
-  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
-  q->grid = ctx->num_cus * per_cu;
   return Status();
 }
 
@@ -1033,9 +1028,89 @@ static Status alloc_gtab(evql_query* q, uint64_t gcap) {
   return Status();
 }
 
+static Status alloc_gtab(evql_query* q, uint64_t gcap);
+Status query_launch(evql_query* q);
+Status query_finish(evql_query* q);
+
+// (re)compiles the fused kernel(s) of q->kp and sizes the persistent grid
+static Status compile_plan_kernels(evql_query* q) {
+  evql_ctx* ctx = q->ctx;
+  q->source = generate_kernel_source(q->kp);
+  Status st = compile_kernel(ctx, q->source, &q->module, true);
+  if (!st.ok()) return st;
+  // persistent grid: one wave of workgroups per CU slot
+  int per_cu = 1;
+  hipError_t oe = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, q->module.fn,
+                                                                     q->kp.block, 0);
+  if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  q->grid = ctx->num_cus * per_cu;
+  return Status();
+}
+
+// Plans without a cardinality hint (the reference's planner has none): before the
+// first full run the fused kernel aggregates a prefix of the scan range, and the
+// number of groups it finds among the passing rows gives the total by the occupancy
+// formula d = G (1 - exp(-p / G)).  A plan whose groups will not fit the LDS tables
+// is re-shaped for the partitioned path (choose_launch_shape) in the same execute.
+static const uint64_t kProbeMinRows = 8ull << 20;  // below this the probe cannot pay
+static const uint64_t kProbeRows = 256ull << 10;
+
+static Status probe_cardinality(evql_query* q) {
+  evql_table* t = q->table;
+  const uint64_t nrows = q->nested ? q->nested_rows : t->layout.num_rows;
+  const uint64_t begin = std::min(q->row_begin, nrows);
+  const uint64_t end = q->row_end ? std::min(q->row_end, nrows) : nrows;
+  if (end - begin < kProbeMinRows) return Status();
+  const uint64_t saved_end = q->row_end;
+  q->row_end = begin + kProbeRows;
+  // room for one group per sampled row
+  Status st = alloc_gtab(q, 4 * kProbeRows);
+  if (!st.ok()) return st;
+  st = query_launch(q);
+  if (st.ok()) st = query_finish(q);
+  q->row_end = saved_end;
+  if (!st.ok()) return st;  // (a division by zero in the prefix is one in the whole scan)
+  const double p = double(q->stats.rows_passed), d = double(q->stats.num_groups);
+  // the group table is rebuilt for the real run
+  hipFree(q->d_gtab);
+  q->d_gtab = nullptr;
+  q->gcap = 0;
+  q->executed = false;
+  if (p < 1 || d < 1) return Status();
+  const double p_total = p * double(end - begin) / double(kProbeRows);
+  double g_est;
+  if (d >= 0.999 * p) {
+    g_est = p_total;  // (nearly) every sampled row its own group
+  } else {
+    // solve d = G (1 - exp(-p / G)) for G >= d by bisection (monotone in G)
+    double lo = d, hi = std::max(p_total, d) * 4 + 16;
+    for (int i = 0; i < 80; ++i) {
+      const double mid = 0.5 * (lo + hi);
+      const double dm = mid * (1.0 - std::exp(-p / mid));
+      if (dm < d) lo = mid; else hi = mid;
+    }
+    g_est = std::min(0.5 * (lo + hi), p_total);
+  }
+  const uint64_t hint = uint64_t(g_est * 1.25) + 16;  // headroom for the estimate's error
+  q->groups_hint = hint;
+  q->stats.estimated_groups = hint;
+  if (hint > 8 * lds_table_max_slots(q->kp) && partitioned_path_possible(q->kp)) {
+    choose_launch_shape(&q->kp, hint);
+    return compile_plan_kernels(q);
+  }
+  return Status();
+}
+
 Status query_launch(evql_query* q) {
   evql_ctx* ctx = q->ctx;
   evql_table* t = q->table;
+  if (!q->probed && q->groups_hint == 0 && q->kp.key_mode != KEY_NONE && !q->within_record) {
+    q->probed = true;
+    Status st = probe_cardinality(q);
+    if (!st.ok()) return st;
+  }
+  q->probed = true;
   const KernelPlan& kp = q->kp;
   hipStream_t s = ctx->stream;
   if (!q->d_gtab) {
@@ -1096,12 +1171,9 @@ Status query_launch(evql_query* q) {
     // count_distinct pair sets: emptied before every launch
     if (q->pairset_cap == 0) {
       const uint64_t span = a.row_end > a.row_begin ? a.row_end - a.row_begin : 0;
+      // starts at <= 2^20 triples; a full set is regrown x4 and the query re-run
       uint64_t cap = 1 << 16;
-      while (cap < 2 * span && cap < (1ull << 22)) cap <<= 1;
-      if (const char* e = getenv("EVQL_PAIRSET_CAP")) {  // tests: force the regrow path
-        cap = 64;
-        while (cap < uint64_t(atoll(e))) cap <<= 1;
-      }
+      while (cap < 2 * span && cap < (1ull << 20)) cap <<= 1;
       q->pairset_cap = cap;
     }
     for (int i = 0; i < kp.n_distinct; ++i) {

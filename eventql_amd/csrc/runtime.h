@@ -219,6 +219,7 @@ struct evql_query {
   uint64_t* d_pairset[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t pairset_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool probed = false;    // cardinality probe done (plans without groups_hint)
   bool launched = false;
   bool executed = false;
   bool fetched = false;  // groups copied to the host (lazy, on first nextBatch)

@@ -398,7 +398,10 @@ typedef struct {
 
   uint32_t group_mode; /* evql_group_mode */
   uint32_t scan_mode;  /* evql_scan_mode  */
-  uint64_t groups_hint; /* expected number of groups; 0 = unknown */
+  uint64_t groups_hint; /* expected number of groups; 0 = unknown (the reference's
+                         * planner has no estimate): the first execute then aggregates
+                         * a 256 Ki-row prefix, estimates the cardinality from the
+                         * groups it finds and picks the LDS or the partitioned path */
 
   /* row range (partition slice) [row_begin, row_end); row_end == 0 => all */
   uint64_t row_begin;
@@ -452,6 +455,8 @@ typedef struct {
   double total_ms;            /* all kernels of the query                   */
   uint32_t n_kernel_launches;
   uint32_t used_lds_table;
+  uint64_t estimated_groups; /* plans without groups_hint: what the sample pass of the
+                              * first execute estimated (0 = no estimate made) */
 } evql_query_stats_t;
 int evql_query_stats(const evql_query_t* q, evql_query_stats_t* out);
 

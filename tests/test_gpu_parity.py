@@ -9,7 +9,7 @@ import pytest
 
 import eventql_amd as E
 from eventql_amd import capi as K, synth, bench_plans as B
-from eventql_amd.plan import Plan, col, count, sum_, min_, max_, mean, If, lit, Call
+from eventql_amd.plan import Plan, col, count, sum_, min_, max_, mean, If, lit, Call, Agg
 import oracle_lib as O
 import tables as T
 
@@ -81,11 +81,10 @@ def test_high_cardinality(mixed):
           group_by=[col("b")], groups_hint=70000)
 
 
-def test_partitioned_high_cardinality_path(mixed, monkeypatch):
+def test_partitioned_high_cardinality_path(mixed):
     """radix-partition + per-bucket LDS aggregation (count / scatter / aggregate
-    kernels), forced on for small group counts too"""
+    kernels): a large groups_hint selects it whatever the data holds"""
     t, img, c = mixed
-    monkeypatch.setenv("EVQL_FORCE_PARTITIONED", "1")
     for kw in (
         dict(select=[col("w"), count(1), sum_(col("a")), sum_(col("v"))], group_by=[col("w")]),
         dict(select=[col("k"), count(1), sum_(col("a")), min_(col("v")), max_(col("b")),
@@ -115,8 +114,8 @@ def test_partitioned_high_cardinality_path(mixed, monkeypatch):
                      groups_hint=100_000))
     assert "evql_part_refine" not in q.kernel_source()
     q.close()
-    monkeypatch.setenv("EVQL_FORCE_PARTITIONED", "0")
-    q = t.query(plan)
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[col("w"), count(1)], group_by=[col("w")],
+                     groups_hint=1000))
     assert "evql_part_scatter" not in q.kernel_source()
     q.close()
 
@@ -446,13 +445,6 @@ def test_count_distinct(mixed, monkeypatch):
     check(t, img, select=[col("s"), cd(a % 100)], group_by=[col("s")])  # string key
     check(t, img, select=[b, cd(k)], group_by=[b], groups_hint=70000)   # 65,536 groups
     check(t, img, select=[k, cd(w) + count(1)], group_by=[k])           # post-aggregate arithmetic
-    # pair set smaller than the data: grown x4 and re-run
-    monkeypatch.setenv("EVQL_PAIRSET_CAP", "1024")
-    q = t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(w)], group_by=[k], row_end=200_000))
-    exp = O.oracle_run(img, Plan(T.MIXED_SCHEMA, select=[k, cd(w)], group_by=[k], row_end=200_000))
-    T.compare_results(q.run().rows(), exp.rows(), exp.types)
-    q.close()
-    monkeypatch.delenv("EVQL_PAIRSET_CAP")
     # the sets stay on one device
     q = t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(a)], group_by=[k]))
     q.execute()
@@ -465,6 +457,28 @@ def test_count_distinct(mixed, monkeypatch):
     with pytest.raises(E.EvqlError) as ei:
         t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(a)], group_by=[k], mode=K.MODE_PARTIAL))
     assert ei.value.code == K.EVQL_ENOTSUP
+
+
+def test_count_distinct_pair_set_regrows(ctx):
+    """more distinct (group, value) pairs than the pair set starts with (2^20): the
+    set is grown x4 and the query re-run"""
+    n = 1_400_000
+    w = E.Writer([dict(name="g", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+                  dict(name="x", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN)])
+    i = np.arange(n, dtype=np.uint64)
+    w.put("g", i % np.uint64(7))
+    w.put("x", i * np.uint64(2654435761))
+    w.commit(n)
+    img = w.image()
+    w.close()
+    S = dict(g=K.T_UINT64, x=K.T_UINT64)
+    plan = Plan(S, select=[col("g"), Agg("count_distinct", col("x")), count(1)], group_by=[col("g")])
+    t = ctx.open_image(img)
+    q = t.query(plan)
+    exp = O.oracle_run(img, plan)
+    T.compare_results(q.run().rows(), exp.rows(), exp.types)
+    q.close()
+    t.close()
 
 
 def test_order_by_limit_above_the_group_by(mixed):
@@ -982,3 +996,40 @@ def test_full_size_properties(ctx):
     assert q.run().rows() == [(n,)]
     q.close()
     t.close()
+
+
+def test_plan_without_a_hint_finds_the_partitioned_path_by_itself(ctx):
+    """groups_hint = 0 (the reference's planner has no cardinality estimate): the
+    first execute aggregates a 256 Ki-row prefix, estimates the number of groups and
+    re-shapes the plan.  3e6 groups over 9e6 rows -> the partitioned kernels; 1000
+    groups over the same rows -> the LDS path stays."""
+    n = 9_000_000
+    t = ctx.generate(n, "kuab", u_mod=3_000_000)
+    try:
+        img = t.download_image()
+        S = dict(k=K.T_UINT64, u=K.T_UINT64, a=K.T_UINT64, b=K.T_UINT64)
+        u, k, a, b = col("u"), col("k"), col("a"), col("b")
+        plan = Plan(S, select=[u, count(1), sum_(a), max_(b)], group_by=[u], where=a > 1000)
+        q = t.query(plan)
+        assert "evql_part_scatter" not in q.kernel_source()
+        got = q.run()
+        st = q.stats()
+        assert "evql_part_scatter" in q.kernel_source()
+        assert 2_000_000 < st["estimated_groups"] < 5_000_000, st
+        exp = O.oracle_run(img, plan)
+        assert got.nrows == exp.nrows
+        T.compare_results(got.rows(), exp.rows(), exp.types)
+        # a second execute of the same operator does not probe again
+        got2 = q.run()
+        assert got2.nrows == exp.nrows
+        q.close()
+        plan = Plan(S, select=[k, count(1), sum_(a)], group_by=[k], where=a > 1000)
+        q = t.query(plan)
+        got = q.run()
+        assert "evql_part_scatter" not in q.kernel_source()
+        assert 900 < q.stats()["estimated_groups"] < 1500
+        exp = O.oracle_run(img, plan)
+        T.compare_results(got.rows(), exp.rows(), exp.types)
+        q.close()
+    finally:
+        t.close()
