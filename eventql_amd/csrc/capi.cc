@@ -16,6 +16,7 @@ Status query_launch(evql_query* q);
 Status query_finish(evql_query* q);
 Status query_reset(evql_query* q);
 Status query_recount(evql_query* q);
+Status query_dense_into_table(evql_query* q);
 Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n, int64_t limit,
                        uint64_t offset);
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows);
@@ -599,6 +600,10 @@ uint32_t evql_query_record_words(const evql_query_t* q) {
 }
 
 int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out) {
+  {
+    Status st = query_dense_into_table(q);
+    if (!st.ok()) return ret(st);
+  }
   out->device_words = q->d_gtab;
   out->capacity = q->gcap + 8;
   out->words_per_group = uint32_t(q->kp.words_per_slot());
@@ -618,16 +623,24 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
   hipStream_t s = q->ctx->stream;
   if (!q->d_gtab || !q->d_counters) return fail(EVQL_EARG, "execute() was not called");
   uint64_t* d_cnt = q->d_counters + 6;  // per-query counter block: no allocation per call
+  const uint32_t nwords = uint32_t(q->kp.words_per_slot());
+  // (partitioned path) the dense records as they are, the table's groups behind them
+  const uint64_t nd = q->dense_n;
+  if (nd > max_groups) return fail(EVQL_ENOMEM, "export buffer too small");
+  uint64_t* dst = static_cast<uint64_t*>(device_dst);
+  if (nd) hipMemcpyAsync(dst, q->d_dense, nd * (nwords + 1) * 8, hipMemcpyDeviceToDevice, s);
   hipMemsetAsync(d_cnt, 0, 8, s);
-  hipError_t e = launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8,
-                                      uint32_t(q->kp.words_per_slot()),
-                                      static_cast<uint64_t*>(device_dst), max_groups, d_cnt, s);
+  hipError_t e = hipSuccess;
   uint64_t n = 0;
-  hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s);
+  if (q->ngroups > nd) {
+    e = launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, nwords, dst + nd * (nwords + 1),
+                             max_groups - nd, d_cnt, s);
+    hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s);
+  }
   hipError_t e2 = hipStreamSynchronize(s);
   if (e != hipSuccess || e2 != hipSuccess) return fail(EVQL_EDEVICE, "export kernel failed");
-  if (n > max_groups) return fail(EVQL_ENOMEM, "export buffer too small");
-  *n_groups = n;
+  if (n > max_groups - nd) return fail(EVQL_ENOMEM, "export buffer too small");
+  *n_groups = n + nd;
   return EVQL_OK;
   API_CATCH
 }
@@ -636,6 +649,10 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
   API_TRY
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   hipStream_t s = q->ctx->stream;
+  {
+    Status st = query_dense_into_table(q);
+    if (!st.ok()) return ret(st);
+  }
   for (int attempt = 0; attempt < 2; ++attempt) {
     MergeArgs a{};
     a.words = q->d_gtab;

@@ -252,6 +252,7 @@ evql_query::~evql_query() {
   if (d_tuples) hipFree(d_tuples);
   if (d_tuples_tmp) hipFree(d_tuples_tmp);
   if (d_part_cursors) hipFree(d_part_cursors);
+  if (d_dense) hipFree(d_dense);
   for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
@@ -1119,6 +1120,9 @@ Status query_launch(evql_query* q) {
     // step (2.7 GB of slots for 1e7 groups at 1/4)
     const uint64_t slack = q->groups_hint >= (1ull << 20) ? 2 : 4;
     uint64_t want = kp.key_mode == KEY_NONE ? 8 : std::max<uint64_t>(q->groups_hint * slack, 1 << 16);
+    // partitioned path: groups leave the LDS tables as dense records; the HBM table
+    // only takes the groups of buckets that overflowed theirs (regrown on demand)
+    if (kp.partitioned) want = 1 << 16;
     uint64_t cap = 8;
     while (cap < want) cap <<= 1;
     Status st = alloc_gtab(q, cap);
@@ -1206,6 +1210,14 @@ Status query_launch(evql_query* q) {
     ap.p.tuples = q->d_tuples;
     ap.p.tuples_tmp = q->d_tuples_tmp;
     ap.p.cursors = q->d_part_cursors;
+    if (!q->d_dense) {
+      q->dense_cap = std::max<uint64_t>(q->groups_hint, 1) * 2 + 4096;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_dense),
+                        q->dense_cap * uint64_t(kp.words_per_slot() + 1) * 8));
+    }
+    ap.p.dense = q->d_dense;
+    ap.p.dense_cap = q->dense_cap;
+    q->dense_n = 0;
     HIP_TRY(hipMemsetAsync(q->d_part_cursors, 0, ncursors * 4, s));
     size_t psz = sizeof(HostArgsWithPart);
     void* pconfig[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ap, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz,
@@ -1288,9 +1300,15 @@ Status query_finish(evql_query* q) {
     HIP_TRY(hipMemcpy(status, q->d_status, 16, hipMemcpyDeviceToHost));
     if (status[0] & 1u) return Status::error(EVQL_ERUNTIME, "division by zero");
     if (status[0] & 4u) return Status::error(EVQL_ERUNTIME, "modulo by zero");
-    if (status[0] & (2u | 8u)) {
-      // group table / count_distinct pair set too small: grow and run again
+    if (status[0] & (2u | 8u | 16u)) {
+      // group table / count_distinct pair set / dense record buffer too small: grow
+      // and run again
       Status st;
+      if (status[0] & 16u) {
+        hipFree(q->d_dense);
+        q->d_dense = nullptr;
+        q->groups_hint = std::max<uint64_t>(q->groups_hint, 1024) * 4;
+      }
       if (status[0] & 2u) {
         st = alloc_gtab(q, q->gcap * 4);
         if (!st.ok()) return st;
@@ -1319,8 +1337,9 @@ Status query_finish(evql_query* q) {
     // when the first nextBatch asks for them (a partial aggregate that is merged
     // on the device never leaves it).  Only the group count is read back: the
     // count pass was enqueued behind the kernels by launch (counter word 4).
-    q->ngroups = counters[4];
-    q->stats.num_groups = counters[4];
+    q->dense_n = q->kp.partitioned ? counters[3] : 0;
+    q->ngroups = counters[4] + q->dense_n;
+    q->stats.num_groups = q->ngroups;
     q->executed = true;
     q->fetched = false;
     q->emit_pos = 0;
@@ -1340,11 +1359,65 @@ Status query_recount(evql_query* q) {
   uint64_t n = 0;
   HIP_TRY(hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  q->ngroups = n;
-  q->stats.num_groups = n;
+  q->ngroups = n + q->dense_n;
+  q->stats.num_groups = q->ngroups;
   q->fetched = false;
   q->executed = true;
   q->emit_pos = 0;
+  return Status();
+}
+
+// the dense records of the partitioned path moved into the (regrown) HBM hash table:
+// what merging another partition's groups into this query needs
+Status query_dense_into_table(evql_query* q) {
+  if (q->dense_n == 0) return Status();
+  evql_ctx* ctx = q->ctx;
+  hipStream_t s = ctx->stream;
+  const KernelPlan& kp = q->kp;
+  const uint32_t nwords = uint32_t(kp.words_per_slot());
+  // groups already in the table (overflowed buckets)
+  uint64_t in_table = q->ngroups - q->dense_n;
+  DevBuf<uint64_t> old_rec;
+  if (in_table) {
+    HIP_TRY(old_rec.alloc(in_table * (nwords + 1) * 8));
+    uint64_t* d_cnt = q->d_counters + 6;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+    HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, nwords, old_rec, in_table, d_cnt, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  uint64_t cap = 1 << 16;
+  while (cap < q->ngroups * 2) cap <<= 1;
+  Status st = alloc_gtab(q, cap);
+  if (!st.ok()) return st;
+  TableInitArgs ia{};
+  ia.words = q->d_gtab;
+  ia.stride = q->gcap + 8;
+  ia.nwords = nwords;
+  ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
+  int w = 1;
+  if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
+  HIP_TRY(launch_table_init(ia, s));
+  MergeArgs a{};
+  a.words = q->d_gtab;
+  a.gcap = q->gcap;
+  a.stride = q->gcap + 8;
+  a.nwords = nwords;
+  w = 1;
+  a.has_ident2 = kp.has_ident2() ? 1 : 0;
+  if (kp.has_ident2()) a.ops[w++] = 255;
+  if (kp.need_first_row) a.ops[w++] = 2;  // min
+  for (const auto& sw : kp.states) a.ops[w++] = uint32_t(sw.op);
+  a.status = q->d_status;
+  HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
+  if (in_table) HIP_TRY(launch_table_merge(a, old_rec, in_table, s));
+  HIP_TRY(launch_table_merge(a, q->d_dense, q->dense_n, s));
+  uint32_t status[4] = {0};
+  HIP_TRY(hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (status[0] & 2u) return Status::error(EVQL_ENOMEM, "group table full");
+  q->dense_n = 0;
   return Status();
 }
 
@@ -1376,6 +1449,7 @@ Status query_reset(evql_query* q) {
   HIP_TRY(hipEventRecord(q->ev1, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   q->ngroups = 0;
+  q->dense_n = 0;
   q->stats.num_groups = 0;
   q->stats.rows_scanned = 0;
   q->stats.rows_passed = 0;
@@ -1399,7 +1473,7 @@ static Status fetch_results(evql_query* q) {
   // the record buffer is sized by the number of groups (counted by finish /
   // recount / reset), not by the table capacity
   uint64_t n = q->stats.num_groups;
-  if (n > maxrec) n = maxrec;
+  if (n > maxrec + q->dense_n) n = maxrec + q->dense_n;
   const uint64_t total_groups = n;
   // small results (the usual case) reuse a per-query 1 MiB buffer: no allocation
   // inside a step
@@ -1413,8 +1487,16 @@ static Status fetch_results(evql_query* q) {
       HIP_TRY(rec_own.alloc(n * (nwords + 1) * 8));
       d_rec = rec_own;
     }
+    // dense records of the partitioned path first, the table's groups behind them
+    const uint64_t nd = std::min(q->dense_n, n);
+    if (nd) {
+      HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * (nwords + 1) * 8, hipMemcpyDeviceToDevice, s));
+    }
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
-    HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec, n, d_cnt, s));
+    if (n > nd) {
+      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec + nd * (nwords + 1),
+                                   n - nd, d_cnt, s));
+    }
   }
   // ORDER BY .. LIMIT: only the offset+limit smallest records by the first sort
   // key (plus, with further sort keys, every tie of the boundary key) leave the

@@ -67,6 +67,8 @@ struct HostPartArgs {
   uint64_t nwg;
   uint64_t* tuples_tmp;
   uint32_t* cursors;
+  uint64_t* dense;
+  uint64_t dense_cap;
 };
 struct HostArgsWithPart {
   HostArgs a;
@@ -188,6 +190,12 @@ struct evql_query {
   uint64_t* d_tuples_tmp = nullptr;  // coarse-bucket order (two-level scatter)
   uint32_t* d_part_cursors = nullptr;
   uint64_t tuples_cap = 0;  // in tuples
+  // partitioned path: the groups of every bucket that fitted its LDS table, as dense
+  // records [kind, identity, (identity 2), (first row), states...]; the HBM table
+  // then only holds the groups of overflowed buckets
+  uint64_t* d_dense = nullptr;
+  uint64_t dense_cap = 0;  // records
+  uint64_t dense_n = 0;
   int n_update_words = 0;   // update words per row (tuple payload)
   // nested (Dremel) scans: flattened per-row SoA columns, one per scan column
   bool nested = false;
