@@ -163,7 +163,8 @@ def main():
     if leb:
         # config 3's table with the reference's DEFAULT integer encoding
         # (UINT64_LEB128, TableSchema.cc:290-316), written by the host writer; the
-        # first operator decodes the three columns to SoA on the device, once
+        # first operator re-encodes the three columns on the device, once, as
+        # bit-packed pages of the narrowest of 8 / 16 / 32 bits
         from eventql_amd import capi as K
         c = synth.table_columns(rows, seed=seed)
         w = E.Writer([dict(name=n, logical_type=K.COL_UNSIGNED_INT,
@@ -328,7 +329,7 @@ def main():
                 "query": query_text,
                 "rows_per_gpu": rows,
                 "columns": ncols,
-                "encodings": ("k, a, b UINT64_LEB128 (decoded to SoA once per table), v FLOAT_IEEE754"
+                "encodings": ("k, a, b UINT64_LEB128 (re-encoded once per table as 16-bit bit-packed pages), v FLOAT_IEEE754"
                               if leb else "UINT64_PLAIN/FLOAT_IEEE754" if not args.k_bits else
                               "k UINT32_BITPACKED(%d bit), others UINT64_PLAIN/FLOAT_IEEE754"
                               % args.k_bits),

@@ -9,6 +9,7 @@ namespace {
 constexpr int kBlock = 256;
 
 __device__ __forceinline__ u64 rt_column_value(const u8* image, const RtColumn& c, u64 i) {
+  if (c.base) image = c.base;
   switch (c.mode) {
     case 0: return evql_plain64(image, (const u64*) c.pages, i);
     case 1: return evql_plain32(image, (const u64*) c.pages, i);
@@ -338,6 +339,22 @@ __global__ void k_string_hash(const u8* image, const u64* pages, const u64* strp
     }
     out[i] = evql_mix64(h);
   }
+}
+
+__global__ void __launch_bounds__(kBlock) k_max_u64(const u64* values, u64 n, u64* out) {
+  u64 m = 0;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 v = values[i];
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    u32 lo = __shfl_xor((u32) m, d, 64), hi = __shfl_xor((u32) (m >> 32), d, 64);
+    const u64 o = (u64) lo | ((u64) hi << 32);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax((unsigned long long*) out, (unsigned long long) m);
 }
 
 // ---- STRING_PLAIN value boundaries (see aot_kernels.h) --------------------------------
@@ -1203,6 +1220,13 @@ hipError_t launch_string_hash(const uint8_t* image, const uint64_t* pages,
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_string_hash, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
                      (const u64*) pages, (const u64*) strpos, (u64) n, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_max_u64(const uint64_t* values, uint64_t n, uint64_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_max_u64, dim3(grid_for(n, kBlock, 4096)), dim3(kBlock), 0, s,
+                     (const u64*) values, (u64) n, (u64*) out);
   return hipGetLastError();
 }
 

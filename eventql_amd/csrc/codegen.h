@@ -21,6 +21,7 @@ struct ColAccess {
   bool from_uint_to_float = false;  // FLOAT64 stype over a uint column: (double) u
   bool string_hash = false;   // STRING column materialised as hash64
   bool string_bytes = false;  // ... and compared bytewise on the device (strpos array)
+  bool packed = false;        // BITPACKED over the runtime's re-encoded copy (LEB128)
   int layout_index = -1;      // index into TableLayout::columns
 };
 

@@ -41,6 +41,9 @@ struct EvqlColArg {
   // STRING columns compared bytewise: per row (len << 40) | position of the first
   // byte in the column's logical byte stream (pages laid end to end), or NULL
   const u64* strpos;
+  // where `pages` offsets count from: the file image, or the private buffer of a
+  // column the runtime re-encoded (LEB128 -> narrow bit-packed)
+  const u8* base;
 };
 
 struct EvqlArgs {

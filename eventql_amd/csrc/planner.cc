@@ -142,6 +142,7 @@ void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
   // loads in flight per lane = columns x unroll; ~16 saturate HBM (measured: 2
   // columns 2.54 ms at unroll 4, 2.43 ms at unroll 8; 4 columns spill at 8)
   kp.unroll = kp.cols.size() <= 2 ? 8 : 4;
+  // (narrow re-encoded columns at unroll 8 spill: config3l 0.39 ms at 4, 0.72 ms at 8)
   kp.lds_slots = 0;
   if (kp.key_mode == KEY_NONE) return;
   // One 1024-thread workgroup per CU owning (almost) the whole 160 KiB LDS: the

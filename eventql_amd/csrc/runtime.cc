@@ -485,6 +485,44 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
   if (c.dlevel_max > 0) {
     HIP_TRY(launch_expand_nullable(t->d_image, src, m.d_tags, d_tiles, n, m.d_values, s));
     HIP_TRY(hipStreamSynchronize(s));
+  } else if (c.storage_type == ColumnEncoding::UINT64_LEB128 && n > 0) {
+    // Required LEB128 column (the reference's default integer encoding,
+    // TableSchema.cc:290-316): keep it in HBM as bit-packed pages of the narrowest
+    // of 8 / 16 / 32 bits that holds its maximum instead of 8-byte words.  The fused
+    // kernel then streams fewer bytes than the LEB128 stream itself holds for
+    // multi-byte values, with a decode of one shift and one mask (widths dividing 32
+    // never straddle a word).  Decoding LEB128 inside the fused kernel instead would
+    // cost ~10 lane-operations per stream byte (terminator scan + extraction) against
+    // the ~12 the chip has per HBM byte at 6.3 TB/s for the whole query.
+    DevBuf<uint64_t> d_max;
+    HIP_TRY(d_max.alloc(8));
+    HIP_TRY(hipMemsetAsync(d_max, 0, 8, s));
+    HIP_TRY(launch_max_u64(m.d_values, n, d_max, s));
+    uint64_t maxv = 0;
+    HIP_TRY(hipMemcpyAsync(&maxv, d_max, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (maxv <= 0xffffffffull) {
+      const uint32_t bits = maxv <= 0xffu ? 8 : (maxv <= 0xffffu ? 16 : 32);
+      const uint64_t nblocks = (n + 127) / 128;
+      const uint64_t page_bytes = 16ull * bits * kBitpackBlocksPerPage;
+      const uint64_t npages = (nblocks + kBitpackBlocksPerPage - 1) / kBitpackBlocksPerPage;
+      // a tile reads up to 8192 rows beyond the last one: zero slack like the image's
+      const uint64_t bytes = 4 + npages * page_bytes + (1 << 20);
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_packed), bytes));
+      HIP_TRY(hipMemsetAsync(m.d_packed, 0, bytes, s));
+      std::vector<uint64_t> offs;
+      for (uint64_t pi = 0; pi < npages; ++pi) offs.push_back(pi == 0 ? 0 : 4 + pi * page_bytes);
+      offs.push_back(offs.back());  // (one past the end stays in bounds)
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_packed_pages), offs.size() * 8));
+      HIP_TRY(hipMemcpyAsync(m.d_packed_pages, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
+      const uint32_t hdr = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+      HIP_TRY(hipMemcpyAsync(m.d_packed, &hdr, 4, hipMemcpyHostToDevice, s));
+      HIP_TRY(launch_wr_bitpack(m.d_packed, m.d_packed_pages, m.d_values, nullptr, n, bits, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      m.packed_bits = bits;
+      hipFree(m.d_values);  // the 8-byte words are not needed any more
+      m.d_values = nullptr;
+    }
   }
   t->materialized[c.name] = std::move(m);
   return Status();
@@ -550,6 +588,12 @@ Status table_rt_column(evql_table* t, const std::string& name, RtColumn* out,
     out->soa = m.d_values;
     out->tags = m.d_tags;
     if (strpos) *strpos = m.d_strpos;
+    if (m.packed_bits) {
+      c.mode = ColAccess::BITPACKED;
+      out->bits = m.packed_bits;
+      out->pages = m.d_packed_pages;
+      out->base = m.d_packed;
+    }
   }
   out->mode = uint32_t(c.mode);
   return Status();
@@ -980,7 +1024,6 @@ static Status compile_plan_kernels(evql_query* q);
 
 Status query_prepare(evql_query* q) {
   evql_table* t = q->table;
-  evql_ctx* ctx = q->ctx;
   if (q->within_record) {
     Status st = materialize_within_record(q);
     if (!st.ok()) return st;
@@ -989,6 +1032,7 @@ Status query_prepare(evql_query* q) {
     if (!st.ok()) return st;
   }
   // resolve bit widths and materialise SoA columns
+  bool repacked = false;
   for (auto& c : q->kp.cols) {
     if (q->nested) break;
     const ColumnLayout& cl = t->layout.columns[c.layout_index];
@@ -1001,7 +1045,18 @@ Status query_prepare(evql_query* q) {
     } else if (c.mode == ColAccess::SOA) {
       Status st = materialize_column(t, c, nullptr);
       if (!st.ok()) return st;
+      const MaterializedColumn& m = t->materialized[c.name];
+      if (m.packed_bits) {  // LEB128 kept as narrow bit-packed pages
+        c.mode = ColAccess::BITPACKED;
+        c.bits = m.packed_bits;
+        c.packed = true;
+        repacked = true;
+      }
     }
+  }
+  if (repacked && !q->kp.partitioned) {
+    // the access modes changed: block / unroll / LDS table are chosen again
+    choose_launch_shape(&q->kp, q->groups_hint);
   }
   Status st = compile_plan_kernels(q);
   if (!st.ok()) return st;
@@ -1158,9 +1213,15 @@ Status query_launch(evql_query* q) {
   a.counters = q->d_counters;
   for (size_t i = 0; i < kp.cols.size(); ++i) {
     const ColAccess& c = kp.cols[i];
+    a.col[i].base = t->d_image;
     if (c.layout_index >= 0) {
       a.col[i].pages = t->d_pages[c.layout_index][0];
       a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
+    }
+    if (c.packed) {
+      const MaterializedColumn& m = t->materialized[c.name];
+      a.col[i].pages = m.d_packed_pages;
+      a.col[i].base = m.d_packed;
     }
     if (q->nested) {
       a.col[i].soa = q->nested_flat[i];
@@ -1585,6 +1646,11 @@ static Status fetch_results(evql_query* q) {
       rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
       rc[c].mode = ca.mode;
       rc[c].bits = ca.bits;
+      if (ca.packed) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].pages = m.d_packed_pages;
+        rc[c].base = m.d_packed;
+      }
       if (q->nested) {
         rc[c].soa = q->nested_flat[c];
       } else if (ca.mode == ColAccess::SOA) {

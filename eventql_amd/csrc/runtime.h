@@ -21,6 +21,7 @@ struct HostColArg {
   const uint8_t* tags;
   uint64_t npages;
   const uint64_t* strpos;
+  const uint8_t* base;
 };
 static const uint32_t EVQL_MAX_COLS_HOST = 16;
 struct HostArgs {
@@ -116,6 +117,12 @@ struct DevBuf {
 struct MaterializedColumn {
   uint64_t* d_values = nullptr;
   uint8_t* d_tags = nullptr;
+  // UINT64_LEB128 re-encoded as bit-packed pages of width 8 / 16 / 32 (the narrowest
+  // that holds the column's maximum; widths that divide 32 decode with one shift):
+  // the fused kernel then reads 1 - 4 bytes per value instead of an 8-byte SoA word
+  uint8_t* d_packed = nullptr;
+  uint64_t* d_packed_pages = nullptr;  // page offsets into d_packed
+  uint32_t packed_bits = 0;
   bool string_hash = false;
   // strings: (len << 40) | byte position of the value in the column's page stream,
   // per row (bytewise compares in the fused kernel, result emission)
@@ -130,12 +137,17 @@ struct MaterializedColumn {
     std::swap(d_tags, o.d_tags);
     std::swap(d_strpos, o.d_strpos);
     std::swap(string_hash, o.string_hash);
+    std::swap(d_packed, o.d_packed);
+    std::swap(d_packed_pages, o.d_packed_pages);
+    std::swap(packed_bits, o.packed_bits);
     return *this;
   }
   ~MaterializedColumn() {
     if (d_values) hipFree(d_values);
     if (d_tags) hipFree(d_tags);
     if (d_strpos) hipFree(d_strpos);
+    if (d_packed) hipFree(d_packed);
+    if (d_packed_pages) hipFree(d_packed_pages);
   }
 };
 
