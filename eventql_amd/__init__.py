@@ -81,6 +81,19 @@ def lib():
     L.evql_writer_image.argtypes = [C.c_void_p, _u64p]
     L.evql_cstable_upgrade.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]
     L.evql_cstable_inspect.argtypes = [C.c_char_p, C.c_uint64, _u64p, C.POINTER(C.c_int)]
+    L.evql_hub_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.evql_hub_destroy.argtypes = [C.c_void_p]
+    L.evql_exchange_create_hub.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.evql_exchange_create_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p,
+                                            C.POINTER(C.c_void_p)]
+    L.evql_exchange_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(K.Transport),
+                                       C.POINTER(C.c_void_p)]
+    L.evql_rccl_unique_id.argtypes = [C.c_char_p]
+    L.evql_exchange_destroy.argtypes = [C.c_void_p]
+    L.evql_exchange_backend.restype = C.c_char_p
+    L.evql_exchange_backend.argtypes = [C.c_void_p]
+    L.evql_query_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.evql_exchange_last_stats.argtypes = [C.c_void_p, C.POINTER(K.ExchangeStats)]
     L.evql_writer_write_file.argtypes = [C.c_void_p, C.c_char_p]
     L.evql_writer_destroy.argtypes = [C.c_void_p]
     L.evql_query_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(K.PlanDesc),
@@ -419,6 +432,11 @@ class Query:
     def import_groups(self, device_ptr, n):
         _check(lib().evql_query_import_groups(self.h, device_ptr, n))
 
+    def exchange(self, x, mode=K.EXCHANGE_GATHER_ALL):
+        """evql_query_exchange (collective): afterwards next_batch yields the merged
+        groups (all of them, or with EXCHANGE_BY_OWNER the key range this rank owns)"""
+        _check(lib().evql_query_exchange(self.h, x.h, mode))
+
     def reset(self):
         """empty group table, no scan: merge target for import_groups"""
         _check(lib().evql_query_reset(self.h))
@@ -527,3 +545,89 @@ def compile_only(plan, columns, cache_dir=None):
     cd = (cache_dir or KERNEL_CACHE_DIR).encode()
     _check(lib().evql_compile_only(C.byref(plan.desc), infos, len(columns), cd, C.byref(size)))
     return size.value
+
+
+class Hub:
+    """evql_hub_*: the in-process rendezvous of nranks contexts driven by one thread each"""
+
+    def __init__(self, nranks):
+        self.h = C.c_void_p()
+        _check(lib().evql_hub_create(nranks, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().evql_hub_destroy(self.h)
+            self.h = None
+
+
+class Exchange:
+    """evql_exchange_*: moves group records between the ranks of a distributed GROUP BY.
+    Exchange.hub(ctx, hub, rank) | Exchange.rccl(ctx, nranks, rank, id128) |
+    Exchange.custom(ctx, nranks, rank, all_gather, all_to_all, name)"""
+
+    def __init__(self, h, keep=None):
+        self.h = h
+        self._keep = keep
+
+    @classmethod
+    def hub(cls, ctx, hub, rank):
+        h = C.c_void_p()
+        _check(lib().evql_exchange_create_hub(ctx.h, hub.h, rank, C.byref(h)))
+        return cls(h)
+
+    @staticmethod
+    def rccl_unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().evql_rccl_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx, nranks, rank, id128):
+        h = C.c_void_p()
+        _check(lib().evql_exchange_create_rccl(ctx.h, nranks, rank, bytes(id128), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def custom(cls, ctx, nranks, rank, all_gather, all_to_all, name="custom"):
+        """all_gather(send: list[int]) -> list[int] (nranks * len(send));
+        all_to_all(d_send, send_counts, d_recv, recv_counts, stream) with raw device
+        addresses and word counts"""
+        def ag(user, send, n, recv):
+            try:
+                out = all_gather([send[i] for i in range(n)])
+                for i, v in enumerate(out):
+                    recv[i] = v
+                return 0
+            except Exception:  # noqa: BLE001 -- must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return K.EVQL_ERUNTIME
+
+        def a2a(user, d_send, sc, d_recv, rc, stream):
+            try:
+                all_to_all(d_send, [sc[i] for i in range(nranks)], d_recv,
+                           [rc[i] for i in range(nranks)], stream)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return K.EVQL_ERUNTIME
+
+        cb1, cb2 = K.ALL_GATHER_FN(ag), K.ALL_TO_ALL_FN(a2a)
+        tr = K.Transport(None, cb1, cb2, name.encode())
+        h = C.c_void_p()
+        _check(lib().evql_exchange_create(ctx.h, nranks, rank, C.byref(tr), C.byref(h)))
+        return cls(h, keep=(cb1, cb2, tr))
+
+    def backend(self):
+        return lib().evql_exchange_backend(self.h).decode()
+
+    def stats(self):
+        s = K.ExchangeStats()
+        _check(lib().evql_exchange_last_stats(self.h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in K.ExchangeStats._fields_}
+
+    def close(self):
+        if self.h:
+            lib().evql_exchange_destroy(self.h)
+            self.h = None

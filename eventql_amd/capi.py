@@ -170,3 +170,24 @@ class PartialView(C.Structure):
 
 
 HEARTBEAT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class ExchangeStats(C.Structure):
+    _fields_ = [("groups_sent", C.c_uint64), ("groups_received", C.c_uint64),
+                ("bytes_sent", C.c_uint64), ("export_ms", C.c_double),
+                ("transfer_ms", C.c_double), ("merge_ms", C.c_double)]
+
+
+EXCHANGE_GATHER_ALL = 0
+EXCHANGE_BY_OWNER = 1
+
+# evql_transport_t callbacks
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64,
+                            C.POINTER(C.c_uint64))
+ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p,
+                            C.POINTER(C.c_uint64), C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather_u64", ALL_GATHER_FN),
+                ("all_to_all_words", ALL_TO_ALL_FN), ("name", C.c_char_p)]

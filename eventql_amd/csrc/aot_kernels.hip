@@ -20,6 +20,11 @@ __device__ __forceinline__ u64 rt_column_value(const u8* image, const RtColumn& 
 
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total);
 
+// byte `pos` of the virtual byte stream over a column's 512 KiB data pages
+__device__ __forceinline__ u8 vbyte_fwd(const u8* image, const u64* pages, u64 pos) {
+  return image[pages[pos >> 19] + (pos & 0x7ffffull)];
+}
+
 // ---- table maintenance -----------------------------------------------------------
 __global__ void k_table_init(TableInitArgs a) {
   // slots of `nwords` adjacent words
@@ -125,6 +130,144 @@ __global__ void k_gather_rows(const u8* image, const RtColumn* cols, u32 ncols,
       const RtColumn col = cols[c];
       out_vals[(u64) c * n + i] = rt_column_value(image, col, r);
       out_tags[(u64) c * n + i] = col.tags ? col.tags[r] : 0;
+    }
+  }
+}
+
+// ---- exchange of group records between GPUs ---------------------------------------
+__device__ __forceinline__ u32 record_owner(const u64* rec, u32 nranks) {
+  // the sentinel / NULL key groups (kind != 0) live on rank 0
+  return rec[0] != 0 ? 0u : (u32) (evql_mix64(rec[1] ^ 0x2545f4914f6cdd1dull) % nranks);
+}
+
+__global__ void __launch_bounds__(kBlock) k_owner_hist(const u64* records, u64 n, u32 rw,
+                                                       u32 nranks, u64* counts) {
+  __shared__ u32 h[kMaxExchangeRanks];
+  if (threadIdx.x < kMaxExchangeRanks) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    atomicAdd(&h[record_owner(records + i * rw, nranks)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nranks && h[threadIdx.x]) {
+    atomicAdd((unsigned long long*) &counts[threadIdx.x], (unsigned long long) h[threadIdx.x]);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_owner_scatter(const u64* records, u64 n, u32 rw,
+                                                          u32 nranks, const u64* starts,
+                                                          u64* cursors, u64* out) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = records + i * rw;
+    const u32 o = record_owner(rec, nranks);
+    const u64 pos = starts[o] + atomicAdd((unsigned long long*) &cursors[o], 1ull);
+    u64* dst = out + pos * rw;
+    for (u32 w = 0; w < rw; ++w) dst[w] = rec[w];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_resolve_records(ResolveArgs a) {
+  const u32 ow = a.in_words + a.ncols + 1;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* in = (const u64*) a.in + i * a.in_words;
+    u64* out = (u64*) a.out + i * ow;
+    for (u32 w = 0; w < a.in_words; ++w) out[w] = in[w];
+    const u64 row = in[a.first_row_word];
+    out[a.first_row_word] = a.rank_tag | row;
+    u64 tags = 0;
+    for (u32 c = 0; c < a.ncols; ++c) {
+      const RtColumn col = a.cols[c];
+      out[a.in_words + c] = rt_column_value(a.image, col, row);
+      if (col.tags && (col.tags[row] & 1)) tags |= 1ull << c;
+    }
+    out[a.in_words + a.ncols] = tags;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_wire_str_sizes(WireStrArgs a) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = (const u64*) a.records + i * a.rw;
+    const u64 tags = rec[a.tags_word];
+    u64 sz = 0;
+    for (u32 k = 0; k < a.nstr; ++k) {
+      if (!((tags >> a.col[k]) & 1)) sz += rec[a.word[k]] >> 40;
+    }
+    a.sizes[i] = sz;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_wire_str_copy(WireStrArgs a) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+       i += (u64) gridDim.x * blockDim.x) {
+    u64* rec = (u64*) a.records + i * a.rw;
+    const u64 tags = rec[a.tags_word];
+    // this record's owner = the bucket its index falls into
+    u32 o = 0;
+    while (o + 1 < a.nranks && i >= a.starts[o + 1]) ++o;
+    const u64 seg0 = ((const u64*) a.sizes)[a.starts[o]];
+    u64 pos = ((const u64*) a.sizes)[i];
+    for (u32 k = 0; k < a.nstr; ++k) {
+      if ((tags >> a.col[k]) & 1) {
+        rec[a.word[k]] = 0;
+        continue;
+      }
+      const u64 sp = rec[a.word[k]];
+      const u64 off = sp & kStrOffMask;
+      const u32 len = (u32) (sp >> 40);
+      for (u32 b = 0; b < len; ++b) a.heap[pos + b] = vbyte_fwd(a.image, (const u64*) a.pages[k], off + b);
+      rec[a.word[k]] = ((u64) len << 40) | (pos - seg0);
+      pos += len;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_table_merge_resolved(MergeResolvedArgs a,
+                                                                 const u64* records, u64 n) {
+  const u32 rw = a.m.nwords + 1;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = records + i * rw;
+    const u64 kind = rec[0], ident = rec[1];
+    u64* words = (u64*) a.m.words;
+    i64 gs;
+    if (kind == 1) {
+      gs = (i64) a.m.gcap;
+      words[(u64) gs * a.m.nwords] = 0;
+    } else if (kind == 2) {
+      gs = (i64) a.m.gcap + 1;
+      words[(u64) gs * a.m.nwords] = 0;
+    } else {
+      gs = a.m.has_ident2 ? evql_gtab_find2(words, a.m.nwords, a.m.gcap, ident, rec[2], evql_mix64(ident))
+                          : evql_gtab_find(words, a.m.nwords, a.m.gcap, ident, evql_mix64(ident));
+    }
+    if (gs < 0) {
+      atomicOr(&a.m.status[0], EVQL_ST_TABLE_FULL);
+      continue;
+    }
+    u64* slot = words + (u64) gs * a.m.nwords;
+    bool first = false;
+    for (u32 w = 1 + a.m.has_ident2; w < a.state_words; ++w) {
+      if (w == a.first_row_word) {
+        const u64 old = atomicMin((unsigned long long*) &slot[w], (unsigned long long) rec[1 + w]);
+        first = old == EVQL_EMPTY;
+      } else {
+        rt_atomic(a.m.ops[w], &slot[w], rec[1 + w]);
+      }
+    }
+    if (first) {
+      // (one record per group and batch, batches merged one after the other: the
+      // first entry of a group has exactly one writer)
+      for (u32 c = 0; c <= a.ncols; ++c) {
+        u64 v = rec[1 + a.state_words + c];
+        if (c < a.ncols && ((a.str_mask >> c) & 1)) {
+          v = (v & ~kStrOffMask) | (((v & kStrOffMask) + a.heap_base) & kStrOffMask);
+        }
+        slot[a.state_words + c] = v;
+      }
     }
   }
 }
@@ -1220,6 +1363,49 @@ hipError_t launch_string_hash(const uint8_t* image, const uint64_t* pages,
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_string_hash, dim3(grid_for(n)), dim3(kBlock), 0, s, image,
                      (const u64*) pages, (const u64*) strpos, (u64) n, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_owner_hist(const uint64_t* records, uint64_t n, uint32_t rw, uint32_t nranks,
+                             uint64_t* counts, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_owner_hist, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), 0, s,
+                     (const u64*) records, (u64) n, rw, nranks, (u64*) counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_owner_scatter(const uint64_t* records, uint64_t n, uint32_t rw, uint32_t nranks,
+                                const uint64_t* starts, uint64_t* cursors, uint64_t* out,
+                                hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_owner_scatter, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) records,
+                     (u64) n, rw, nranks, (const u64*) starts, (u64*) cursors, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve_records(const ResolveArgs& a, hipStream_t s) {
+  if (a.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_resolve_records, dim3(grid_for(a.n)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_wire_str_sizes(const WireStrArgs& a, hipStream_t s) {
+  if (a.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wire_str_sizes, dim3(grid_for(a.n)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_wire_str_copy(const WireStrArgs& a, hipStream_t s) {
+  if (a.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wire_str_copy, dim3(grid_for(a.n)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_table_merge_resolved(const MergeResolvedArgs& a, const uint64_t* records,
+                                       uint64_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_table_merge_resolved, dim3(grid_for(n)), dim3(kBlock), 0, s, a,
+                     (const u64*) records, (u64) n);
   return hipGetLastError();
 }
 

@@ -1,0 +1,587 @@
+// exchange.cc -- the exchange step of a GROUP BY that ran on several GPUs.
+//
+// The reference fans partial aggregates in over TCP: every partition's
+// PartialGroupByExpression rows travel as EVQL_OP_QUERY_PARTIALAGGR frames to the
+// coordinator's GroupByMergeExpression (sql/statements/select/groupby.cc:438-472,
+// 528-637; server/sql/scheduler.cc:117-162).  Here a partition's groups sit in the HBM
+// of the GPU that scanned it, as dense records [kind, identity, (identity 2), (first
+// row), states...]; they are bucketed by owner on the device, moved GPU to GPU (RCCL
+// send/recv over xGMI, or peer copies inside one process) and merged with one kernel
+// launch per source rank, in rank order, into a fresh table.
+#include <rccl/rccl.h>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include "runtime.h"
+
+using namespace evql;
+
+namespace evql {
+Status query_dense_into_table(evql_query* q);
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      return Status::error(EVQL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    }                                                                                       \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// in-process hub: ranks are threads of one process
+// ---------------------------------------------------------------------------------------
+struct evql_hub {
+  int nranks = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  std::vector<const uint64_t*> host_send;              // all_gather
+  std::vector<const uint64_t*> dev_send;               // all_to_all: packed send buffers
+  std::vector<std::vector<uint64_t>> send_counts;      // [src][dst]
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t gen = generation;
+    if (++arrived == nranks) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+struct evql_exchange {
+  evql_ctx* ctx = nullptr;
+  int nranks = 1, rank = 0;
+  evql_transport_t tr{};
+  std::string name;
+  // built-in transports
+  evql_hub* hub = nullptr;
+  ncclComm_t comm = nullptr;
+  uint64_t* d_scratch = nullptr;  // rccl all_gather of counts
+  evql_exchange_stats_t stats{};
+};
+
+namespace {
+
+int hub_all_gather(void* user, const uint64_t* send, uint64_t n, uint64_t* recv) {
+  evql_exchange* x = static_cast<evql_exchange*>(user);
+  evql_hub* h = x->hub;
+  h->host_send[x->rank] = send;
+  h->barrier();
+  for (int r = 0; r < x->nranks; ++r) memcpy(recv + uint64_t(r) * n, h->host_send[r], n * 8);
+  h->barrier();
+  return EVQL_OK;
+}
+
+int hub_all_to_all(void* user, const uint64_t* d_send, const uint64_t* send_counts, uint64_t* d_recv,
+                   const uint64_t* recv_counts, void* stream) {
+  evql_exchange* x = static_cast<evql_exchange*>(user);
+  evql_hub* h = x->hub;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the send buffer has to be complete before another rank's thread reads it
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(EVQL_EDEVICE, "hub: stream sync failed");
+  h->dev_send[x->rank] = d_send;
+  h->send_counts[x->rank].assign(send_counts, send_counts + x->nranks);
+  h->barrier();
+  uint64_t roff = 0;
+  for (int r = 0; r < x->nranks; ++r) {
+    uint64_t soff = 0;
+    for (int d = 0; d < x->rank; ++d) soff += h->send_counts[r][d];
+    const uint64_t cnt = h->send_counts[r][x->rank];
+    if (cnt != recv_counts[r]) return fail(EVQL_ERUNTIME, "hub: counts disagree");
+    if (cnt && hipMemcpyAsync(d_recv + roff, h->dev_send[r] + soff, cnt * 8, hipMemcpyDefault, s) !=
+                   hipSuccess) {
+      return fail(EVQL_EDEVICE, "hub: device copy failed");
+    }
+    roff += cnt;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(EVQL_EDEVICE, "hub: stream sync failed");
+  h->barrier();  // nobody reuses a send buffer before everyone has copied from it
+  return EVQL_OK;
+}
+
+int rccl_all_gather(void* user, const uint64_t* send, uint64_t n, uint64_t* recv) {
+  evql_exchange* x = static_cast<evql_exchange*>(user);
+  hipStream_t s = x->ctx->stream;
+  if (n > 512) return fail(EVQL_EARG, "rccl all_gather: too many words");
+  uint64_t* d_send = x->d_scratch;
+  uint64_t* d_recv = x->d_scratch + 512;
+  if (hipMemcpyAsync(d_send, send, n * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+    return fail(EVQL_EDEVICE, "rccl all_gather: copy failed");
+  }
+  if (ncclAllGather(d_send, d_recv, n, ncclUint64, x->comm, s) != ncclSuccess) {
+    return fail(EVQL_EDEVICE, "ncclAllGather failed");
+  }
+  if (hipMemcpyAsync(recv, d_recv, uint64_t(x->nranks) * n * 8, hipMemcpyDeviceToHost, s) !=
+          hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    return fail(EVQL_EDEVICE, "rccl all_gather: copy back failed");
+  }
+  return EVQL_OK;
+}
+
+int rccl_all_to_all(void* user, const uint64_t* d_send, const uint64_t* send_counts, uint64_t* d_recv,
+                    const uint64_t* recv_counts, void* stream) {
+  evql_exchange* x = static_cast<evql_exchange*>(user);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // xGMI is point to point: one send and one receive per peer, all in flight at once
+  if (ncclGroupStart() != ncclSuccess) return fail(EVQL_EDEVICE, "ncclGroupStart failed");
+  uint64_t soff = 0, roff = 0;
+  for (int r = 0; r < x->nranks; ++r) {
+    if (send_counts[r]) ncclSend(d_send + soff, send_counts[r], ncclUint64, r, x->comm, s);
+    if (recv_counts[r]) ncclRecv(d_recv + roff, recv_counts[r], ncclUint64, r, x->comm, s);
+    soff += send_counts[r];
+    roff += recv_counts[r];
+  }
+  if (ncclGroupEnd() != ncclSuccess) return fail(EVQL_EDEVICE, "ncclGroupEnd failed");
+  return EVQL_OK;
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// -----------------------------------------------------------------------------------------
+// the exchange itself
+// -----------------------------------------------------------------------------------------
+Status exchange(evql_query* q, evql_exchange* x, int mode) {
+  evql_ctx* ctx = q->ctx;
+  evql_table* t = q->table;
+  hipStream_t s = ctx->stream;
+  const KernelPlan& kp = q->kp;
+  const int N = x->nranks;
+  if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
+  if (kp.n_distinct) return Status::error(EVQL_ENOTSUP, "count_distinct sets do not travel");
+  if (N > int(kMaxExchangeRanks)) return Status::error(EVQL_EARG, "too many ranks");
+  if (q->merged) return Status::error(EVQL_EARG, "the query was exchanged already");
+  const uint32_t W = uint32_t(kp.words_per_slot());
+  const uint32_t nc = uint32_t(kp.cols.size());
+  const bool resolved = kp.need_first_row;
+  const uint32_t rw_in = W + 1;
+  const uint32_t rw = resolved ? rw_in + nc + 1 : rw_in;  // wire record words
+  auto t0 = std::chrono::steady_clock::now();
+  x->stats = evql_exchange_stats_t{};
+
+  // ---- 1. this rank's groups as dense records ---------------------------------------------
+  const uint64_t n = q->ngroups;
+  DevBuf<uint64_t> d_rec;
+  HIP_TRY(d_rec.alloc(std::max<uint64_t>(n, 1) * rw_in * 8));
+  {
+    const uint64_t nd = std::min(q->dense_n, n);
+    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
+    if (n > nd) {
+      uint64_t* d_cnt = q->d_counters + 6;
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, W, d_rec.p + nd * rw_in, n - nd,
+                                   d_cnt, s));
+    }
+  }
+  // ---- 2. first-row values into the records (plans that need them) -------------------------
+  DevBuf<uint64_t> d_wire;
+  uint64_t str_mask = 0;
+  std::vector<uint32_t> str_cols;
+  if (resolved) {
+    std::vector<RtColumn> rc(nc);
+    for (uint32_t c = 0; c < nc; ++c) {
+      const ColAccess& ca = kp.cols[c];
+      rc[c] = RtColumn{};
+      rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
+      rc[c].mode = ca.mode;
+      rc[c].bits = ca.bits;
+      if (q->nested) {
+        rc[c].mode = ColAccess::SOA;
+        rc[c].soa = q->nested_flat[c];
+      } else if (ca.packed) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].pages = m.d_packed_pages;
+        rc[c].base = m.d_packed;
+      } else if (ca.mode == ColAccess::SOA) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].soa = ca.string_hash ? m.d_strpos : m.d_values;
+        rc[c].tags = m.d_tags;
+      }
+      if (ca.string_hash) {
+        str_mask |= 1ull << c;
+        str_cols.push_back(c);
+      }
+    }
+    if (str_cols.size() > kMaxWireStrCols) {
+      return Status::error(EVQL_ENOTSUP, "too many string columns in an exchanged plan");
+    }
+    DevBuf<RtColumn> d_cols;
+    HIP_TRY(d_cols.alloc(std::max<uint32_t>(nc, 1) * sizeof(RtColumn)));
+    HIP_TRY(hipMemcpyAsync(d_cols, rc.data(), nc * sizeof(RtColumn), hipMemcpyHostToDevice, s));
+    HIP_TRY(d_wire.alloc(std::max<uint64_t>(n, 1) * rw * 8));
+    ResolveArgs ra{};
+    ra.image = t->d_image;
+    ra.cols = d_cols;
+    ra.ncols = nc;
+    ra.in_words = rw_in;
+    ra.first_row_word = uint32_t(1 + kp.first_row_word());
+    ra.rank_tag = uint64_t(x->rank) << 44;
+    ra.in = d_rec;
+    ra.n = n;
+    ra.out = d_wire;
+    HIP_TRY(launch_resolve_records(ra, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (d_cols / rc live until here)
+  }
+  const uint64_t* d_src = resolved ? d_wire.p : d_rec.p;
+
+  // ---- 3. bucket by owner ---------------------------------------------------------------------
+  std::vector<uint64_t> send_counts(N, 0), starts(N + 1, 0);
+  DevBuf<uint64_t> d_send, d_aux;
+  HIP_TRY(d_send.alloc(std::max<uint64_t>(n, 1) * rw * 8));
+  HIP_TRY(d_aux.alloc((3 * kMaxExchangeRanks + 4) * 8));
+  uint64_t* d_counts = d_aux.p;
+  uint64_t* d_starts = d_aux.p + kMaxExchangeRanks;
+  uint64_t* d_cursors = d_aux.p + 2 * kMaxExchangeRanks + 2;
+  if (mode == EVQL_EXCHANGE_BY_OWNER && N > 1) {
+    HIP_TRY(hipMemsetAsync(d_aux, 0, (3 * kMaxExchangeRanks + 4) * 8, s));
+    HIP_TRY(launch_owner_hist(d_src, n, rw, uint32_t(N), d_counts, s));
+    HIP_TRY(hipMemcpyAsync(send_counts.data(), d_counts, N * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int r = 0; r < N; ++r) starts[r + 1] = starts[r] + send_counts[r];
+    HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), (N + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_owner_scatter(d_src, n, rw, uint32_t(N), d_starts, d_cursors, d_send, s));
+  } else {
+    // every rank gets every record: "bucket" r = all of them
+    HIP_TRY(hipMemcpyAsync(d_send, d_src, n * rw * 8, hipMemcpyDeviceToDevice, s));
+    for (int r = 0; r < N; ++r) send_counts[r] = n;
+    starts[0] = 0;
+    for (int r = 1; r <= N; ++r) starts[r] = n;  // (one segment)
+  }
+  const bool by_owner = mode == EVQL_EXCHANGE_BY_OWNER && N > 1;
+
+  // ---- 4. string bytes of the records, in record order ------------------------------------------
+  DevBuf<uint64_t> d_sizes;
+  DevBuf<uint8_t> d_heap;
+  std::vector<uint64_t> heap_counts(N, 0);  // bytes per destination (padded to words)
+  uint64_t heap_bytes = 0;
+  if (resolved && !str_cols.empty() && n) {
+    WireStrArgs wa{};
+    wa.image = t->d_image;
+    wa.records = d_send;
+    wa.n = n;
+    wa.rw = rw;
+    wa.tags_word = rw_in + nc;
+    wa.nstr = uint32_t(str_cols.size());
+    for (size_t k = 0; k < str_cols.size(); ++k) {
+      wa.word[k] = rw_in + str_cols[k];
+      wa.col[k] = str_cols[k];
+      wa.pages[k] = t->d_pages[kp.cols[str_cols[k]].layout_index][0];
+    }
+    HIP_TRY(d_sizes.alloc((n + 2) * 8));
+    wa.sizes = d_sizes;
+    wa.nranks = by_owner ? uint32_t(N) : 1u;
+    std::vector<uint64_t> seg(N + 1, 0);
+    if (by_owner) {
+      seg = starts;
+    } else {
+      seg[1] = n;
+    }
+    HIP_TRY(hipMemcpyAsync(d_starts, seg.data(), (N + 1) * 8, hipMemcpyHostToDevice, s));
+    wa.starts = d_starts;
+    HIP_TRY(launch_wire_str_sizes(wa, s));
+    HIP_TRY(launch_exclusive_scan(d_sizes, n, d_sizes.p + n, s));
+    HIP_TRY(hipMemcpyAsync(&heap_bytes, d_sizes.p + n, 8, hipMemcpyDeviceToHost, s));
+    // segment borders in bytes
+    std::vector<uint64_t> segoff(N + 1, 0);
+    HIP_TRY(hipStreamSynchronize(s));
+    const int nseg = by_owner ? N : 1;
+    for (int r = 1; r <= nseg; ++r) {
+      if (seg[r] >= n) {
+        segoff[r] = heap_bytes;
+      } else {
+        HIP_TRY(hipMemcpy(&segoff[r], d_sizes.p + seg[r], 8, hipMemcpyDeviceToHost));
+      }
+    }
+    HIP_TRY(d_heap.alloc(heap_bytes + 8 * (N + 1)));
+    wa.heap = d_heap;
+    HIP_TRY(launch_wire_str_copy(wa, s));
+    for (int r = 0; r < N; ++r) {
+      heap_counts[r] = by_owner ? segoff[r + 1] - segoff[r] : heap_bytes;
+    }
+    // (segments are sent as whole words: their starts have to be 8-aligned -- they are
+    // re-packed below)
+  }
+  x->stats.export_ms = ms_since(t0);
+  auto t1 = std::chrono::steady_clock::now();
+
+  // ---- 5. counts, then the records (and the string bytes) --------------------------------------
+  // per destination: [record count, heap bytes]
+  std::vector<uint64_t> mine(2 * N), all(uint64_t(2) * N * N);
+  for (int r = 0; r < N; ++r) {
+    mine[2 * r] = by_owner ? send_counts[r] : n;
+    mine[2 * r + 1] = heap_counts[r];
+  }
+  int rc = x->tr.all_gather_u64(x->tr.user, mine.data(), 2 * N, all.data());
+  if (rc != EVQL_OK) return Status::error(rc, "exchange: all_gather of the counts failed");
+  std::vector<uint64_t> recv_rec(N), recv_heap(N), send_words(N), recv_words(N);
+  uint64_t total_rec = 0, total_heap_words = 0;
+  for (int r = 0; r < N; ++r) {
+    recv_rec[r] = all[uint64_t(r) * 2 * N + 2 * x->rank];
+    recv_heap[r] = all[uint64_t(r) * 2 * N + 2 * x->rank + 1];
+    total_rec += recv_rec[r];
+    total_heap_words += (recv_heap[r] + 7) / 8;
+    send_words[r] = mine[2 * r] * rw;
+    recv_words[r] = recv_rec[r] * rw;
+  }
+  DevBuf<uint64_t> d_recv;
+  HIP_TRY(d_recv.alloc(std::max<uint64_t>(total_rec, 1) * rw * 8));
+  if (by_owner) {
+    rc = x->tr.all_to_all_words(x->tr.user, d_send, send_words.data(), d_recv, recv_words.data(), s);
+  } else {
+    // GATHER_ALL: the same n records to everybody -- as an all-to-all whose send
+    // segments coincide (the transports read `send_counts[r]` words at the running
+    // offset, so the buffer is replicated per destination only logically)
+    DevBuf<uint64_t> d_rep;
+    HIP_TRY(d_rep.alloc(std::max<uint64_t>(n * rw * N, 1) * 8));
+    for (int r = 0; r < N; ++r) {
+      HIP_TRY(hipMemcpyAsync(d_rep.p + uint64_t(r) * n * rw, d_send, n * rw * 8,
+                             hipMemcpyDeviceToDevice, s));
+    }
+    rc = x->tr.all_to_all_words(x->tr.user, d_rep, send_words.data(), d_recv, recv_words.data(), s);
+    if (rc == EVQL_OK) HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (rc != EVQL_OK) return Status::error(rc, "exchange: transfer of the records failed");
+  // string heaps: word-aligned segments
+  DevBuf<uint64_t> d_hsend, d_hrecv;
+  std::vector<uint64_t> hbase(N, 0);
+  if (resolved && !str_cols.empty()) {
+    std::vector<uint64_t> hs(N), hr(N);
+    uint64_t tot = 0;
+    for (int r = 0; r < N; ++r) {
+      hs[r] = (heap_counts[r] + 7) / 8;
+      hr[r] = (recv_heap[r] + 7) / 8;
+      tot += hs[r];
+    }
+    HIP_TRY(d_hsend.alloc(std::max<uint64_t>(tot, 1) * 8));
+    HIP_TRY(d_hrecv.alloc(std::max<uint64_t>(total_heap_words, 1) * 8));
+    uint64_t woff = 0, boff = 0;
+    for (int r = 0; r < N; ++r) {
+      if (heap_counts[r]) {
+        HIP_TRY(hipMemcpyAsync(d_hsend.p + woff, d_heap.p + (by_owner ? boff : 0), heap_counts[r],
+                               hipMemcpyDeviceToDevice, s));
+      }
+      woff += hs[r];
+      if (by_owner) boff += heap_counts[r];
+    }
+    rc = x->tr.all_to_all_words(x->tr.user, d_hsend, hs.data(), d_hrecv, hr.data(), s);
+    if (rc != EVQL_OK) return Status::error(rc, "exchange: transfer of the strings failed");
+    uint64_t b = 0;
+    for (int r = 0; r < N; ++r) {
+      hbase[r] = b;
+      b += hr[r] * 8;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  x->stats.transfer_ms = ms_since(t1);
+  auto t2 = std::chrono::steady_clock::now();
+  x->stats.groups_sent = by_owner ? n : n * uint64_t(N);
+  x->stats.groups_received = total_rec;
+  for (int r = 0; r < N; ++r) {
+    if (r != x->rank) x->stats.bytes_sent += send_words[r] * 8 + heap_counts[r];
+  }
+
+  // ---- 6. merge, one batch per source rank, in rank order, into a fresh table --------------------
+  const uint32_t mw = resolved ? W + nc + 1 : W;  // slot words of the merged table
+  uint64_t cap = 1 << 16;
+  while (cap < total_rec * 2) cap <<= 1;
+  if (q->d_mtab) hipFree(q->d_mtab);
+  q->d_mtab = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mtab), (cap + 8) * uint64_t(mw) * 8));
+  q->mcap = cap;
+  q->m_words = mw;
+  TableInitArgs ia{};
+  ia.words = q->d_mtab;
+  ia.stride = cap + 8;
+  ia.nwords = mw;
+  ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
+  int w = 1;
+  if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  static const uint64_t kIdent[8] = {0, 0, 0xFFFFFFFFFFFFFFFFull, 0, 0x7FFFFFFFFFFFFFFFull,
+                                     0x8000000000000000ull, 0x7FF0000000000000ull,
+                                     0xFFF0000000000000ull};
+  for (const auto& sw : kp.states) ia.identity[w++] = kIdent[sw.op & 7];
+  for (; w < int(mw); ++w) ia.identity[w] = 0;
+  if (mw > kMaxStateWords + 3) return Status::error(EVQL_ENOTSUP, "too many words per merged group");
+  HIP_TRY(launch_table_init(ia, s));
+  MergeResolvedArgs ma{};
+  ma.m.words = q->d_mtab;
+  ma.m.gcap = cap;
+  ma.m.stride = cap + 8;
+  ma.m.nwords = mw;
+  ma.m.has_ident2 = kp.has_ident2() ? 1 : 0;
+  w = 1;
+  if (kp.has_ident2()) ma.m.ops[w++] = 255;
+  if (kp.need_first_row) ma.m.ops[w++] = 2;
+  for (const auto& sw : kp.states) ma.m.ops[w++] = uint32_t(sw.op);
+  ma.m.status = q->d_status;
+  ma.state_words = W;
+  ma.first_row_word = resolved ? uint32_t(kp.first_row_word()) : 0xffffffffu;
+  ma.ncols = nc;
+  ma.str_mask = str_mask;
+  HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
+  uint64_t roff = 0;
+  for (int r = 0; r < N; ++r) {
+    if (recv_rec[r]) {
+      if (resolved) {
+        ma.heap_base = hbase[r];
+        HIP_TRY(launch_table_merge_resolved(ma, d_recv.p + roff * rw, recv_rec[r], s));
+      } else {
+        HIP_TRY(launch_table_merge(ma.m, d_recv.p + roff * rw, recv_rec[r], s));
+      }
+    }
+    roff += recv_rec[r];
+  }
+  uint32_t status[4] = {0};
+  HIP_TRY(hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s));
+  uint64_t* d_cnt = q->d_counters + 4;
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+  HIP_TRY(launch_table_compact(q->d_mtab, cap, cap + 8, mw, nullptr, 0, d_cnt, s));
+  uint64_t ng = 0;
+  HIP_TRY(hipMemcpyAsync(&ng, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (status[0] & 2u) return Status::error(EVQL_ENOMEM, "merged group table full");
+  // the received string bytes are what the merged groups' string words point into
+  q->m_heap.clear();
+  if (resolved && !str_cols.empty() && total_heap_words) {
+    q->m_heap.resize(total_heap_words * 8);
+    HIP_TRY(hipMemcpy(q->m_heap.data(), d_hrecv, total_heap_words * 8, hipMemcpyDeviceToHost));
+  }
+  q->merged = true;
+  q->ngroups = ng;
+  q->stats.num_groups = ng;
+  q->fetched = false;
+  q->emit_pos = 0;
+  x->stats.merge_ms = ms_since(t2);
+  return Status();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int evql_exchange_create(evql_ctx_t* ctx, int nranks, int rank, const evql_transport_t* transport,
+                         evql_exchange_t** out) {
+  if (!ctx || !transport || !out || nranks < 1 || rank < 0 || rank >= nranks ||
+      !transport->all_gather_u64 || !transport->all_to_all_words) {
+    return fail(EVQL_EARG, "bad arguments");
+  }
+  evql_exchange* x = new evql_exchange();
+  x->ctx = ctx;
+  x->nranks = nranks;
+  x->rank = rank;
+  x->tr = *transport;
+  x->name = transport->name ? transport->name : "custom";
+  *out = x;
+  return EVQL_OK;
+}
+
+int evql_hub_create(int nranks, evql_hub_t** out) {
+  if (nranks < 1 || !out) return fail(EVQL_EARG, "bad arguments");
+  evql_hub* h = new evql_hub();
+  h->nranks = nranks;
+  h->host_send.assign(nranks, nullptr);
+  h->dev_send.assign(nranks, nullptr);
+  h->send_counts.assign(nranks, std::vector<uint64_t>(nranks, 0));
+  *out = h;
+  return EVQL_OK;
+}
+
+void evql_hub_destroy(evql_hub_t* hub) { delete hub; }
+
+int evql_exchange_create_hub(evql_ctx_t* ctx, evql_hub_t* hub, int rank, evql_exchange_t** out) {
+  if (!ctx || !hub || !out || rank < 0 || rank >= hub->nranks) return fail(EVQL_EARG, "bad arguments");
+  evql_exchange* x = new evql_exchange();
+  x->ctx = ctx;
+  x->nranks = hub->nranks;
+  x->rank = rank;
+  x->hub = hub;
+  x->tr.user = x;
+  x->tr.all_gather_u64 = hub_all_gather;
+  x->tr.all_to_all_words = hub_all_to_all;
+  x->name = "hub";
+  *out = x;
+  return EVQL_OK;
+}
+
+int evql_rccl_unique_id(void* id128) {
+  if (!id128) return fail(EVQL_EARG, "null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return fail(EVQL_EDEVICE, "ncclGetUniqueId failed");
+  memcpy(id128, &id, sizeof(id));
+  return EVQL_OK;
+}
+
+int evql_exchange_create_rccl(evql_ctx_t* ctx, int nranks, int rank, const void* id128,
+                              evql_exchange_t** out) {
+  if (!ctx || !id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) {
+    return fail(EVQL_EARG, "bad arguments");
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  evql_exchange* x = new evql_exchange();
+  x->ctx = ctx;
+  x->nranks = nranks;
+  x->rank = rank;
+  if (ncclCommInitRank(&x->comm, nranks, id, rank) != ncclSuccess) {
+    delete x;
+    return fail(EVQL_EDEVICE, "ncclCommInitRank failed");
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&x->d_scratch), (512 + 512 * kMaxExchangeRanks) * 8) !=
+      hipSuccess) {
+    ncclCommDestroy(x->comm);
+    delete x;
+    return fail(EVQL_EDEVICE, "hipMalloc failed");
+  }
+  x->tr.user = x;
+  x->tr.all_gather_u64 = rccl_all_gather;
+  x->tr.all_to_all_words = rccl_all_to_all;
+  x->name = "rccl";
+  *out = x;
+  return EVQL_OK;
+}
+
+void evql_exchange_destroy(evql_exchange_t* x) {
+  if (!x) return;
+  if (x->comm) ncclCommDestroy(x->comm);
+  if (x->d_scratch) hipFree(x->d_scratch);
+  delete x;
+}
+
+const char* evql_exchange_backend(const evql_exchange_t* x) { return x ? x->name.c_str() : ""; }
+
+int evql_query_exchange(evql_query_t* q, evql_exchange_t* x, int mode) {
+  if (!q || !x) return fail(EVQL_EARG, "null argument");
+  if (mode != EVQL_EXCHANGE_GATHER_ALL && mode != EVQL_EXCHANGE_BY_OWNER) {
+    return fail(EVQL_EARG, "bad exchange mode");
+  }
+  try {
+    if (hipSetDevice(q->ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
+    Status st = exchange(q, x, mode);
+    if (!st.ok()) return fail(st.code, st.msg);
+    return EVQL_OK;
+  } catch (const std::exception& e) {
+    return fail(EVQL_ERUNTIME, e.what());
+  }
+}
+
+int evql_exchange_last_stats(const evql_exchange_t* x, evql_exchange_stats_t* out) {
+  if (!x || !out) return fail(EVQL_EARG, "null argument");
+  *out = x->stats;
+  return EVQL_OK;
+}
+
+}  // extern "C"

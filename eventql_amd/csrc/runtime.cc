@@ -253,6 +253,7 @@ evql_query::~evql_query() {
   if (d_tuples_tmp) hipFree(d_tuples_tmp);
   if (d_part_cursors) hipFree(d_part_cursors);
   if (d_dense) hipFree(d_dense);
+  if (d_mtab) hipFree(d_mtab);
   for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
@@ -1167,6 +1168,7 @@ Status query_launch(evql_query* q) {
     if (!st.ok()) return st;
   }
   q->probed = true;
+  q->merged = false;
   const KernelPlan& kp = q->kp;
   hipStream_t s = ctx->stream;
   if (!q->d_gtab) {
@@ -1511,6 +1513,7 @@ Status query_reset(evql_query* q) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   q->ngroups = 0;
   q->dense_n = 0;
+  q->merged = false;
   q->stats.num_groups = 0;
   q->stats.rows_scanned = 0;
   q->stats.rows_passed = 0;
@@ -1526,15 +1529,20 @@ static Status fetch_results(evql_query* q) {
   evql_table* t = q->table;
   const KernelPlan& kp = q->kp;
   hipStream_t s = ctx->stream;
-  const uint32_t nwords = uint32_t(kp.words_per_slot());
-  const uint64_t stride = q->gcap + 8;
-  const uint64_t maxrec = q->gcap + 2;
+  // after an exchange the groups live in the merged table (wider slots)
+  const bool merged = q->merged;
+  const uint32_t nwords = merged ? q->m_words : uint32_t(kp.words_per_slot());
+  uint64_t* const gtab = merged ? q->d_mtab : q->d_gtab;
+  const uint64_t gcap = merged ? q->mcap : q->gcap;
+  const uint64_t stride = gcap + 8;
+  const uint64_t maxrec = gcap + 2;
+  const uint64_t dense_n = merged ? 0 : q->dense_n;
   uint64_t* d_rec = nullptr;
   uint64_t* d_cnt = q->d_counters + 5;
   // the record buffer is sized by the number of groups (counted by finish /
   // recount / reset), not by the table capacity
   uint64_t n = q->stats.num_groups;
-  if (n > maxrec + q->dense_n) n = maxrec + q->dense_n;
+  if (n > maxrec + dense_n) n = maxrec + dense_n;
   const uint64_t total_groups = n;
   // small results (the usual case) reuse a per-query 1 MiB buffer: no allocation
   // inside a step
@@ -1549,13 +1557,13 @@ static Status fetch_results(evql_query* q) {
       d_rec = rec_own;
     }
     // dense records of the partitioned path first, the table's groups behind them
-    const uint64_t nd = std::min(q->dense_n, n);
+    const uint64_t nd = std::min(dense_n, n);
     if (nd) {
       HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * (nwords + 1) * 8, hipMemcpyDeviceToDevice, s));
     }
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
     if (n > nd) {
-      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, stride, nwords, d_rec + nd * (nwords + 1),
+      HIP_TRY(launch_table_compact(gtab, gcap, stride, nwords, d_rec + nd * (nwords + 1),
                                    n - nd, d_cnt, s));
     }
   }
@@ -1608,6 +1616,7 @@ static Status fetch_results(evql_query* q) {
     n = m;
   }
   q->ngroups = n;
+  q->rec_stride = nwords + 1;
   q->records.assign(n * (nwords + 1), 0);
   if (n) {
     HIP_TRY(hipMemcpyAsync(q->records.data(), d_rec, n * (nwords + 1) * 8,
@@ -1635,7 +1644,31 @@ static Status fetch_results(evql_query* q) {
   // first-row values of every scan column
   q->first_vals.clear();
   q->first_tags.clear();
-  if (kp.need_first_row && n) {
+  if (kp.need_first_row && n && merged) {
+    // the merged records carry the first-row values themselves: one word per scan
+    // column, one word of NULL-tag bits; string words point into the received bytes
+    const uint32_t nc = uint32_t(kp.cols.size());
+    const size_t rw = nwords + 1, fr0 = size_t(kp.words_per_slot()) + 1;
+    q->first_vals.resize(n * nc);
+    q->first_tags.resize(n * nc);
+    q->first_str_off.assign(n * nc, 0);
+    q->first_str_heap = q->m_heap;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t* rec = &q->records[i * rw];
+      const uint64_t tags = rec[fr0 + nc];
+      for (uint32_t c = 0; c < nc; ++c) {
+        q->first_vals[uint64_t(c) * n + i] = rec[fr0 + c];
+        q->first_tags[uint64_t(c) * n + i] = uint8_t((tags >> c) & 1);
+        if (kp.cols[c].string_hash) {
+          const uint64_t off = rec[fr0 + c] & kStrOffMask;
+          if (off + (rec[fr0 + c] >> 40) > q->first_str_heap.size()) {
+            return Status::error(EVQL_ERUNTIME, "exchange: string offset outside the received bytes");
+          }
+          q->first_str_off[uint64_t(c) * n + i] = off;
+        }
+      }
+    }
+  } else if (kp.need_first_row && n) {
     const uint32_t nc = uint32_t(kp.cols.size());
     std::vector<uint64_t> rows(n);
     const size_t rw = nwords + 1;
@@ -1953,7 +1986,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
   const size_t nsel = q->select.size();
   const bool partial = q->group_mode == EVQL_MODE_PARTIAL;
   q->out_cols.assign(partial ? 2 : nsel, std::vector<uint8_t>());
-  const size_t rw = size_t(kp.words_per_slot()) + 1;
+  const size_t rw = q->rec_stride;
   const uint32_t nc = uint32_t(kp.cols.size());
   size_t emitted = 0;
   std::vector<Value> scan_vals(nc), sel_inputs(q->scan_select.size());
@@ -2069,7 +2102,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
 static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* outs) {
   const KernelPlan& kp = q->kp;
   const size_t nsel = q->select.size();
-  const size_t rw = size_t(kp.words_per_slot()) + 1;
+  const size_t rw = q->rec_stride;
   const uint32_t nc = uint32_t(kp.cols.size());
   const uint64_t* rec = &q->records[g * rw];
   const uint64_t kind = rec[0], ident = rec[1];

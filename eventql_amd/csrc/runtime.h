@@ -208,6 +208,14 @@ struct evql_query {
   uint64_t* d_dense = nullptr;
   uint64_t dense_cap = 0;  // records
   uint64_t dense_n = 0;
+  // after evql_query_exchange: the merged groups of all ranks (or of this rank's key
+  // range) in a table of their own, whose slots also carry the first-row value words
+  // of plans that need them (exchange.cc); results are then emitted from here
+  bool merged = false;
+  uint64_t* d_mtab = nullptr;
+  uint64_t mcap = 0;
+  uint32_t m_words = 0;
+  std::vector<uint8_t> m_heap;  // received string bytes
   int n_update_words = 0;   // update words per row (tuple payload)
   // nested (Dremel) scans: flattened per-row SoA columns, one per scan column
   bool nested = false;
@@ -246,6 +254,7 @@ struct evql_query {
   int grid = 0;
   // results
   std::vector<uint64_t> records;  // dense [kind, ident, (first_row), states...]
+  size_t rec_stride = 0;          // words per fetched record (>= words_per_slot + 1)
   uint64_t ngroups = 0;
   std::vector<uint64_t> first_vals;  // [col][group]
   std::vector<uint8_t> first_tags;

@@ -493,6 +493,84 @@ uint32_t evql_query_record_words(const evql_query_t* q);
  * merge target of partial aggregates (GroupByMergeExpression, groupby.cc:528-637) */
 int evql_query_reset(evql_query_t* q);
 
+/* ------------------------------------------------------------------------ */
+/* the exchange step between the GPUs of a node                               */
+/*   the reference fans partial aggregates in over TCP: PartialGroupByExpression */
+/*   rows -> EVQL_OP_QUERY_PARTIALAGGR frames -> GroupByMergeExpression          */
+/*   (groupby.cc:438-472, 528-637; server/sql/scheduler.cc:117-162).  Here every  */
+/*   partition's groups sit in the HBM of the GPU that scanned it and travel as   */
+/*   device buffers.                                                              */
+/* ------------------------------------------------------------------------ */
+/*
+ * A transport moves device memory between the ranks (one rank = one evql_ctx = one
+ * GPU).  Built in: RCCL over xGMI for one process per GPU (evql_exchange_create_rccl)
+ * and an in-process hub for one process driving several contexts from one thread per
+ * rank (evql_hub_*; the EventQL server itself runs partitions as threads of one
+ * process).  Anything else can be plugged in through the callbacks.  A callback
+ * returns 0 or an evql_status.
+ */
+typedef struct {
+  void* user;
+  /* every rank contributes n words of HOST memory; recv gets nranks * n words in
+   * rank order */
+  int (*all_gather_u64)(void* user, const uint64_t* send, uint64_t n, uint64_t* recv);
+  /* variable all-to-all of DEVICE memory in 8-byte words: send_counts[r] words go to
+   * rank r from d_send (packed in rank order), recv_counts[r] words arrive from rank r
+   * in d_recv (packed in rank order).  d_send is complete on `hip_stream`; d_recv
+   * must be complete on it (or the call synchronous) on return */
+  int (*all_to_all_words)(void* user, const uint64_t* d_send, const uint64_t* send_counts,
+                          uint64_t* d_recv, const uint64_t* recv_counts, void* hip_stream);
+  const char* name; /* "rccl", "hub", ... reported by evql_exchange_backend */
+} evql_transport_t;
+
+typedef struct evql_exchange evql_exchange_t;
+typedef struct evql_hub evql_hub_t;
+
+int evql_exchange_create(evql_ctx_t* ctx, int nranks, int rank, const evql_transport_t* transport,
+                         evql_exchange_t** out);
+/* RCCL: rank 0 makes the id (128 bytes, ncclUniqueId) and hands it to the others out
+ * of band (the launcher's rendezvous); collective: every rank calls _create_rccl */
+int evql_rccl_unique_id(void* id128);
+int evql_exchange_create_rccl(evql_ctx_t* ctx, int nranks, int rank, const void* id128,
+                              evql_exchange_t** out);
+/* in-process hub: nranks contexts (same or different devices) in ONE process, every
+ * rank's calls on its own thread; copies are device-to-device (peer) copies */
+int evql_hub_create(int nranks, evql_hub_t** out);
+void evql_hub_destroy(evql_hub_t* hub);
+int evql_exchange_create_hub(evql_ctx_t* ctx, evql_hub_t* hub, int rank, evql_exchange_t** out);
+void evql_exchange_destroy(evql_exchange_t* x);
+const char* evql_exchange_backend(const evql_exchange_t* x);
+
+typedef enum {
+  /* low cardinality: every rank ends up with every group (the reference's
+   * coordinator; any rank may emit the result) */
+  EVQL_EXCHANGE_GATHER_ALL = 0,
+  /* high cardinality: group records are bucketed on the device by owner =
+   * hash(identity) % nranks; every rank ends up with the groups it owns and emits
+   * them through next_batch -- the result stays distributed */
+  EVQL_EXCHANGE_BY_OWNER = 1
+} evql_exchange_mode;
+
+/*
+ * Collective, after execute() on every rank (same plan everywhere, each over its own
+ * partition): exports this rank's groups, exchanges them and merges what arrives
+ * (mergeInstance per aggregate, groupby.cc:577-612) -- batches in RANK ORDER into a
+ * fresh table, so that a float sum is added up in the same order on every rank and
+ * in every run of the same partial aggregates.  Plans that read first-row values
+ * (string / multi-column keys, non-aggregate select expressions) carry them in the
+ * records: the first row of the lowest rank that has the group wins, strings travel
+ * as bytes.  next_batch then yields the merged groups.  count_distinct: EVQL_ENOTSUP.
+ */
+int evql_query_exchange(evql_query_t* q, evql_exchange_t* x, int mode);
+
+typedef struct {
+  uint64_t groups_sent;     /* records this rank exported */
+  uint64_t groups_received; /* records merged here (own ones included) */
+  uint64_t bytes_sent;      /* record + string bytes that left this rank */
+  double export_ms, transfer_ms, merge_ms;
+} evql_exchange_stats_t;
+int evql_exchange_last_stats(const evql_exchange_t* x, evql_exchange_stats_t* out);
+
 /*
  * GroupByMergeExpression over partial aggregates that arrive as BYTES
  * (groupby.cc:493-672): the coordinator's merge of PartialGroupBy rows from
