@@ -110,6 +110,11 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(QUERIES))
     ap.add_argument("--cpu-sample-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --rows per GPU; strong: --rows in total, split over the GPUs")
+    ap.add_argument("--no-hint", action="store_true",
+                    help="plans without groups_hint (the reference's planner has none): the "
+                         "first execute estimates the cardinality itself")
     ap.add_argument("--k-bits", type=int, default=0,
                     help="config2 run B (SURVEY.md 8d): k as UINT32_BITPACKED of this width")
     args = ap.parse_args()
@@ -117,7 +122,7 @@ def main():
     import torch
     import torch.distributed as dist
     import eventql_amd as E
-    from eventql_amd import bench_plans as B, distributed as D, synth
+    from eventql_amd import bench_plans as B, capi as K, distributed as D, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,10 +151,13 @@ def main():
     # config 4 = 1.25e8 rows per partition, config 5 = 1e8 records
     rows = args.rows or (125_000_000 if high_card else
                          (100_000_000 if nested or args.workload == "config3l" else 1_000_000_000))
+    if args.scaling == "strong":
+        rows = rows // world  # the job's rows are fixed, every rank scans its share
     plan_fn = {"config2": B.config2, "config3": B.config3, "config3l": B.config3,
                "config5": config5_plan, "config5w": config5w_plan,
-               "config4": lambda **kw: B.config4(groups_hint=n_keys, **kw),
-               "config4s": lambda **kw: B.config4s(groups_hint=n_keys, **kw)}[args.workload]
+               "config4": lambda **kw: B.config4(groups_hint=0 if args.no_hint else n_keys, **kw),
+               "config4s": lambda **kw: B.config4s(groups_hint=0 if args.no_hint else n_keys, **kw)
+               }[args.workload]
     gen_kw = dict(u_mod=n_keys) if high_card else {}
     if args.k_bits:
         gen_kw["k_bits"] = args.k_bits
@@ -202,17 +210,10 @@ def main():
     q = table.query(plan_fn())
     ctx.synchronize()
     first_operator_ms = (time.perf_counter() - t0q) * 1e3
-    rw = q.record_words()
-    qm = None
-    if world > 1 and high_card:
-        qm = table.query(plan_fn())       # merge target: this rank's key range
-        send = torch.zeros((n_keys + 16) * rw, dtype=torch.int64, device="cuda")
-    elif world > 1:
-        max_groups = 4096
-        send = torch.zeros(max_groups * rw, dtype=torch.int64, device="cuda")
-        # RCCL: persistent exchange buffers, records exported straight behind the
-        # count word (no staging copy, no allocation inside the timed step)
-        xbuf = D.exchange_buffers(rw, max_groups, world, "cuda") if backend == "nccl" else None
+    # N > 1: the exchange step runs behind the C ABI (evql_query_exchange): RCCL
+    # send/recv between the GPUs, python only hands the ncclUniqueId around
+    xchg = D.make_exchange(ctx) if world > 1 else None
+    xmode = K.EXCHANGE_BY_OWNER if high_card else K.EXCHANGE_GATHER_ALL
 
     def drain(qq):
         n = 0
@@ -243,25 +244,11 @@ def main():
             # 1e7 result rows are not pulled through nextBatch inside the timed
             # region (the reference puts ORDER BY / LIMIT above such a GROUP BY)
             return q.stats()["num_groups"] if high_card else drain(q)
-        if not high_card:
-            # partial aggregates -> dense records -> every rank -> merge kernel
-            if xbuf is not None:
-                n = q.export_groups(xbuf[0].data_ptr() + 8, max_groups)
-                parts = D.exchange_all_gather(None, n, rw, max_groups, buffers=xbuf)
-            else:
-                n = q.export_groups(send.data_ptr(), max_groups)
-                parts = D.exchange_all_gather(send, n, rw, max_groups)
-            foreign, cnt = D.gather_foreign(parts, rank, rw)
-            if cnt:
-                q.import_groups(foreign.data_ptr(), cnt)
-            return drain(q)
-        # high cardinality: hash-partitioned all-to-all, each rank merges its range
-        n = q.export_groups(send.data_ptr(), n_keys + 16)
-        recv, cnt = D.exchange_all_to_all(send, n, rw)
-        qm.reset()
-        if cnt:
-            qm.import_groups(recv.data_ptr(), cnt)
-        return qm.stats()["num_groups"]   # result stays distributed over the ranks
+        # partial aggregates -> records bucketed by owner (high cardinality) or sent to
+        # everybody (low) -> merged in rank order; low: rank 0's result is the answer,
+        # high: the result stays distributed over the ranks
+        q.exchange(xchg, xmode)
+        return q.stats()["num_groups"] if high_card else drain(q)
 
     for _ in range(args.warmup):
         step()
@@ -306,8 +293,11 @@ def main():
                 traffic = None
         merge = "none"
         if world > 1:
-            merge = ("rccl all_to_all of hash-partitioned group records + merge kernel"
-                     if high_card else "rccl all_gather of dense group records + merge kernel")
+            merge = ("%s: group records bucketed by owner on the device, all-to-all, merged in "
+                     "rank order" if high_card else
+                     "%s: every rank's group records to every rank, merged in rank order"
+                     ) % xchg.backend()
+            out_x = xchg.stats()
         out = {
             # BASELINE.json's metric, quoted on config3; the other workloads say what they are
             "metric": ("rows/sec scanned+aggregated, 1e9-row 4-col GROUP BY"
@@ -320,7 +310,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64/f64",
             "data": "synthetic",
@@ -336,6 +326,7 @@ def main():
                 "groups": int(ngroups_out),
                 "partitions": world,
                 "merge": merge,
+                "groups_hint": "none (estimated by the first execute)" if args.no_hint else "given",
             },
             "roofline": {
                 "bound": "hbm",
@@ -380,6 +371,8 @@ def main():
             else:
                 sample = args.cpu_sample_rows or (4_000_000 if high_card else 80_000_000)
                 out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
+        if world > 1:
+            out["config"]["exchange_last_step"] = out_x
         if leb or string_keys:
             out["config"]["materialize_ms_first_operator"] = materialize_ms
         if string_keys:

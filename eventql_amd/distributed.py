@@ -1,19 +1,20 @@
-"""Partial-aggregate exchange across ranks (one process per GPU).
+"""Launcher-side plumbing of a GROUP BY over several partitions, one process per GPU.
 
-The reference splits a GROUP BY into per-partition `PartialGroupByExpression`s
-and merges their (key, saved state) rows in `GroupByMergeExpression`
-(sql/statements/select/groupby.cc:438-472, 553-615; fan-out in
-server/sql/scheduler.cc:117-162).  Here the partitions live on different GPUs
-and the rows travel as dense group records `[kind, identity, (first_row),
-state words...]` (int64 words) over torch.distributed -- RCCL on GPUs, gloo in
-the CPU tests:
+The reference splits a GROUP BY into per-partition `PartialGroupByExpression`s and
+merges their rows in `GroupByMergeExpression` (sql/statements/select/groupby.cc:231-714;
+fan-out in server/sql/scheduler.cc:117-162).  Here the exchange step itself --
+bucketing the group records by owner, moving them between GPUs, merging them in rank
+order -- is `evql_query_exchange` behind the C ABI (csrc/exchange.cc).  Python only
 
-  low cardinality   all_gather of every rank's records, each rank merges the
-                    others' (`exchange_all_gather`)
-  high cardinality  records are bucketed by `identity % world` and exchanged
-                    with all_to_all so that every rank owns a disjoint key range
-                    (`exchange_all_to_all`)
+  * assigns partitions to ranks (`partitions_for_rank`),
+  * hands the ncclUniqueId of rank 0 to the other ranks through the launcher's
+    rendezvous (`torch.distributed`, any backend) for the built-in RCCL transport, and
+  * for rehearsals without one GPU per rank (`gloo`: several ranks on one GPU, or the
+    CPU tests) supplies the two transport callbacks on top of torch.distributed,
+    staging device memory through the host.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -25,126 +26,82 @@ def partitions_for_rank(n_partitions, rank, world):
     return list(range(lo, min(lo + per, n_partitions)))
 
 
-def _staged_on_host(records, group):
-    """gloo moves host memory: device records are staged through the host (used
-    to rehearse the multi-rank path on a single GPU; RCCL needs one GPU per rank)"""
-    return records.device.type == "cuda" and dist.get_backend(group) == "gloo"
+def _words(ptr, nwords, device):
+    """int64 tensor view of `nwords` 8-byte words at raw address `ptr`"""
+    nwords = int(nwords)
+    if nwords == 0:
+        return torch.zeros(0, dtype=torch.int64, device=device)
+    if device == "cpu":
+        buf = (C.c_int64 * nwords).from_address(int(ptr))
+        return torch.frombuffer(buf, dtype=torch.int64)
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = dict(shape=(nwords,), typestr="<i8", data=(int(ptr), False),
+                                      version=2)
+    return torch.as_tensor(h, device=device)
 
 
-def exchange_buffers(record_words, max_groups, world, device):
-    """persistent (send, recv) buffers for exchange_all_gather: word 0 of a rank's
-    slice = its record count, the records follow -- export straight into
-    send[1:] (data_ptr() + 8) and pass the pair as `buffers`"""
-    width = max_groups * record_words + 1
-    return (torch.zeros(width, dtype=torch.int64, device=device),
-            torch.zeros(world * width, dtype=torch.int64, device=device))
+class GlooTransport:
+    """evql_transport_t callbacks over torch.distributed point-to-point transfers
+    (gloo moves host memory: device words are staged through the host)"""
+
+    def __init__(self, group=None, device="cuda"):
+        self.group = group
+        self.device = device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, send):
+        t = torch.tensor([int(v) & 0x7FFFFFFFFFFFFFFF if v >= 1 << 63 else int(v) for v in send],
+                         dtype=torch.int64)
+        parts = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return [int(v) for p in parts for v in p.tolist()]
+
+    def all_to_all(self, d_send, send_counts, d_recv, recv_counts, stream):
+        if self.device != "cpu":
+            torch.cuda.synchronize()
+        send = _words(d_send, sum(send_counts), self.device)
+        recv = _words(d_recv, sum(recv_counts), self.device)
+        host_send = send.cpu() if self.device != "cpu" else send
+        outs, reqs = [], []
+        soff = roff = 0
+        for r in range(self.world):
+            sc, rc = int(send_counts[r]), int(recv_counts[r])
+            piece = host_send[soff:soff + sc]
+            if r == self.rank:
+                outs.append((roff, piece.clone()))
+            else:
+                if sc:
+                    reqs.append(dist.isend(piece.contiguous(), r, group=self.group))
+                if rc:
+                    buf = torch.zeros(rc, dtype=torch.int64)
+                    reqs.append(dist.irecv(buf, r, group=self.group))
+                    outs.append((roff, buf))
+            soff += sc
+            roff += rc
+        for q in reqs:
+            q.wait()
+        for off, buf in outs:
+            if buf.numel():
+                recv[off:off + buf.numel()].copy_(buf)
+        if self.device != "cpu":
+            torch.cuda.synchronize()
 
 
-def exchange_all_gather(records, n, record_words, max_groups, group=None, buffers=None):
-    """records: int64 tensor holding >= n*record_words words (this rank's dense
-    records), or None when they were exported into buffers[0][1:] already.
-    Returns [(tensor_view, count)] for every rank, in rank order."""
-    if records is not None and _staged_on_host(records, group):
-        parts = exchange_all_gather(records[:n * record_words].cpu(), n, record_words,
-                                    max_groups, group)
-        return [(t.to(records.device), c) for t, c in parts]
-    world = dist.get_world_size(group)
-    width = max_groups * record_words + 1
-    if n > max_groups:
-        raise ValueError("more groups (%d) than the exchange buffer holds (%d)" % (n, max_groups))
-    if buffers is not None:
-        send, recv = buffers
-        send[0] = n
-        if records is not None:
-            send[1:1 + n * record_words] = records[:n * record_words]
-    else:
-        send = torch.zeros(width, dtype=torch.int64, device=records.device)
-        send[0] = n
-        send[1:1 + n * record_words] = records[:n * record_words]
-        recv = torch.zeros(world * width, dtype=torch.int64, device=records.device)
-    if send.device.type == "cuda":
-        dist.all_gather_into_tensor(recv, send, group=group)
-    else:
-        parts = [torch.zeros(width, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(parts, send, group=group)
-        recv = torch.cat(parts)
-    out = []
-    recv = recv.view(world, width)
-    counts = recv[:, 0].tolist()  # one device->host sync for all ranks
-    for r in range(world):
-        cnt = int(counts[r])
-        out.append((recv[r, 1:1 + cnt * record_words], cnt))
-    return out
-
-
-def gather_foreign(parts, rank, record_words):
-    """the other ranks' records of an exchange_all_gather as ONE contiguous tensor
-    (a single merge launch instead of one per rank); (tensor | None, count)"""
-    others = [t for r, (t, c) in enumerate(parts) if r != rank and c]
-    if not others:
-        return None, 0
-    cat = others[0].contiguous() if len(others) == 1 else torch.cat(others)
-    if cat.device.type == "cuda":
-        # the merge kernel runs on the library's own stream
-        torch.cuda.current_stream(cat.device).synchronize()
-    return cat, cat.numel() // record_words
-
-
-def bucket_by_owner(records, n, record_words, world):
-    """stable partition of dense records by owner rank = identity % world
-    (records with kind != 0, i.e. the sentinel / NULL key, go to rank 0)"""
-    rec = records[:n * record_words].view(n, record_words)
-    ident = rec[:, 1]
-    owner = torch.remainder(ident, world)
-    owner = torch.where(rec[:, 0] != 0, torch.zeros_like(owner), owner)
-    order = torch.argsort(owner, stable=True)
-    counts = torch.bincount(owner, minlength=world)
-    return rec[order].contiguous().view(-1), counts
-
-
-def exchange_all_to_all(records, n, record_words, group=None):
-    """hash-partitioned exchange: returns (tensor, count) of the records this rank
-    owns, received from all ranks (its own included)"""
-    if _staged_on_host(records, group):
-        recv, cnt = exchange_all_to_all(records[:n * record_words].cpu(), n, record_words, group)
-        return recv.to(records.device), cnt
-    world = dist.get_world_size(group)
-    send, counts = bucket_by_owner(records, n, record_words, world)
-    counts_cpu = counts.to("cpu")
-    recv_counts = torch.zeros(world, dtype=torch.int64, device=records.device)
-    if records.device.type == "cuda":
-        dist.all_to_all_single(recv_counts, counts, group=group)
-    else:
-        outs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-        ins = [counts[r:r + 1].clone() for r in range(world)]
-        _all_to_all_lists(outs, ins, group)
-        recv_counts = torch.cat(outs)
-    in_split = [int(c) * record_words for c in counts_cpu.tolist()]
-    out_split = [int(c) * record_words for c in recv_counts.to("cpu").tolist()]
-    recv = torch.zeros(sum(out_split), dtype=torch.int64, device=records.device)
-    if records.device.type == "cuda":
-        dist.all_to_all_single(recv, send, out_split, in_split, group=group)
-    else:
-        outs = [torch.zeros(s, dtype=torch.int64) for s in out_split]
-        ins = list(torch.split(send, in_split))
-        _all_to_all_lists(outs, ins, group)
-        recv = torch.cat(outs) if outs else recv
-    return recv, sum(out_split) // record_words
-
-
-def _all_to_all_lists(outs, ins, group):
-    """gloo has no all_to_all: emulate with point-to-point transfers (empty
-    messages are skipped on both sides; the sizes are known from the counts)"""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    reqs = []
-    for r in range(world):
-        if r == rank:
-            outs[r].copy_(ins[r])
-            continue
-        if ins[r].numel():
-            reqs.append(dist.isend(ins[r].contiguous(), r, group=group))
-        if outs[r].numel():
-            reqs.append(dist.irecv(outs[r], r, group=group))
-    for q in reqs:
-        q.wait()
+def make_exchange(ctx, group=None):
+    """the evql Exchange of this rank: RCCL when the process group is `nccl` (one GPU
+    per rank; the id travels through the group), the gloo callbacks otherwise"""
+    import eventql_amd as E
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        box = [E.Exchange.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return E.Exchange.rccl(ctx, world, rank, box[0])
+    tr = GlooTransport(group, "cuda")
+    x = E.Exchange.custom(ctx, world, rank, tr.all_gather, tr.all_to_all, name="gloo (host staged)")
+    x._transport = tr
+    return x
