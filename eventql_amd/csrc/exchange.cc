@@ -64,6 +64,43 @@ struct evql_exchange {
   ncclComm_t comm = nullptr;
   uint64_t* d_scratch = nullptr;  // rccl all_gather of counts
   evql_exchange_stats_t stats{};
+  // device buffers of the exchange step, kept (and only ever grown) between calls:
+  // a step of a running query allocates nothing
+  struct Slot {
+    void* p = nullptr;
+    size_t cap = 0;
+  };
+  Slot ws[12];
+  hipError_t get(int slot, size_t bytes, void** out) {
+    Slot& sl = ws[slot];
+    if (bytes > sl.cap) {
+      if (sl.p) hipFree(sl.p);
+      sl.p = nullptr;
+      sl.cap = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      hipError_t e = hipMalloc(&sl.p, want);
+      if (e != hipSuccess) return e;
+      sl.cap = want;
+    }
+    *out = sl.p;
+    return hipSuccess;
+  }
+  ~evql_exchange() {
+    for (auto& sl : ws) {
+      if (sl.p) hipFree(sl.p);
+    }
+  }
+};
+
+// a typed view of a workspace slot with DevBuf's interface
+template <typename T>
+struct WsBuf {
+  evql_exchange* x;
+  int slot;
+  T* p = nullptr;
+  WsBuf(evql_exchange* xx, int s) : x(xx), slot(s) {}
+  hipError_t alloc(size_t bytes) { return x->get(slot, bytes ? bytes : 8, reinterpret_cast<void**>(&p)); }
+  operator T*() const { return p; }
 };
 
 namespace {
@@ -169,7 +206,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
 
   // ---- 1. this rank's groups as dense records ---------------------------------------------
   const uint64_t n = q->ngroups;
-  DevBuf<uint64_t> d_rec;
+  WsBuf<uint64_t> d_rec(x, 0);
   HIP_TRY(d_rec.alloc(std::max<uint64_t>(n, 1) * rw_in * 8));
   {
     const uint64_t nd = std::min(q->dense_n, n);
@@ -182,7 +219,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     }
   }
   // ---- 2. first-row values into the records (plans that need them) -------------------------
-  DevBuf<uint64_t> d_wire;
+  WsBuf<uint64_t> d_wire(x, 1);
   uint64_t str_mask = 0;
   std::vector<uint32_t> str_cols;
   if (resolved) {
@@ -213,7 +250,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     if (str_cols.size() > kMaxWireStrCols) {
       return Status::error(EVQL_ENOTSUP, "too many string columns in an exchanged plan");
     }
-    DevBuf<RtColumn> d_cols;
+    WsBuf<RtColumn> d_cols(x, 2);
     HIP_TRY(d_cols.alloc(std::max<uint32_t>(nc, 1) * sizeof(RtColumn)));
     HIP_TRY(hipMemcpyAsync(d_cols, rc.data(), nc * sizeof(RtColumn), hipMemcpyHostToDevice, s));
     HIP_TRY(d_wire.alloc(std::max<uint64_t>(n, 1) * rw * 8));
@@ -234,7 +271,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
 
   // ---- 3. bucket by owner ---------------------------------------------------------------------
   std::vector<uint64_t> send_counts(N, 0), starts(N + 1, 0);
-  DevBuf<uint64_t> d_send, d_aux;
+  WsBuf<uint64_t> d_send(x, 3), d_aux(x, 4);
   HIP_TRY(d_send.alloc(std::max<uint64_t>(n, 1) * rw * 8));
   HIP_TRY(d_aux.alloc((3 * kMaxExchangeRanks + 4) * 8));
   uint64_t* d_counts = d_aux.p;
@@ -258,8 +295,8 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   const bool by_owner = mode == EVQL_EXCHANGE_BY_OWNER && N > 1;
 
   // ---- 4. string bytes of the records, in record order ------------------------------------------
-  DevBuf<uint64_t> d_sizes;
-  DevBuf<uint8_t> d_heap;
+  WsBuf<uint64_t> d_sizes(x, 5);
+  WsBuf<uint8_t> d_heap(x, 6);
   std::vector<uint64_t> heap_counts(N, 0);  // bytes per destination (padded to words)
   uint64_t heap_bytes = 0;
   if (resolved && !str_cols.empty() && n) {
@@ -331,7 +368,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     send_words[r] = mine[2 * r] * rw;
     recv_words[r] = recv_rec[r] * rw;
   }
-  DevBuf<uint64_t> d_recv;
+  WsBuf<uint64_t> d_recv(x, 7);
   HIP_TRY(d_recv.alloc(std::max<uint64_t>(total_rec, 1) * rw * 8));
   if (by_owner) {
     rc = x->tr.all_to_all_words(x->tr.user, d_send, send_words.data(), d_recv, recv_words.data(), s);
@@ -339,7 +376,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     // GATHER_ALL: the same n records to everybody -- as an all-to-all whose send
     // segments coincide (the transports read `send_counts[r]` words at the running
     // offset, so the buffer is replicated per destination only logically)
-    DevBuf<uint64_t> d_rep;
+    WsBuf<uint64_t> d_rep(x, 8);
     HIP_TRY(d_rep.alloc(std::max<uint64_t>(n * rw * N, 1) * 8));
     for (int r = 0; r < N; ++r) {
       HIP_TRY(hipMemcpyAsync(d_rep.p + uint64_t(r) * n * rw, d_send, n * rw * 8,
@@ -350,7 +387,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   }
   if (rc != EVQL_OK) return Status::error(rc, "exchange: transfer of the records failed");
   // string heaps: word-aligned segments
-  DevBuf<uint64_t> d_hsend, d_hrecv;
+  WsBuf<uint64_t> d_hsend(x, 9), d_hrecv(x, 10);
   std::vector<uint64_t> hbase(N, 0);
   if (resolved && !str_cols.empty()) {
     std::vector<uint64_t> hs(N), hr(N);
@@ -392,9 +429,11 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   const uint32_t mw = resolved ? W + nc + 1 : W;  // slot words of the merged table
   uint64_t cap = 1 << 16;
   while (cap < total_rec * 2) cap <<= 1;
-  if (q->d_mtab) hipFree(q->d_mtab);
-  q->d_mtab = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mtab), (cap + 8) * uint64_t(mw) * 8));
+  if (!q->d_mtab || q->mcap != cap || q->m_words != mw) {
+    if (q->d_mtab) hipFree(q->d_mtab);
+    q->d_mtab = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mtab), (cap + 8) * uint64_t(mw) * 8));
+  }
   q->mcap = cap;
   q->m_words = mw;
   TableInitArgs ia{};

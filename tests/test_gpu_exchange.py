@@ -223,3 +223,34 @@ def test_custom_transport_callbacks():
     assert all(o is not None for o in out)
     union = out[0] + out[1]
     T.compare_results(union, exp.rows(), exp.types, key_cols=1)
+
+
+def test_rccl_transport_single_rank(ctx):
+    """the built-in RCCL transport (ncclCommInitRank, grouped ncclSend / ncclRecv,
+    ncclAllGather) with one rank on the one GPU of this box: everything is sent to
+    itself, which drives the same calls as N ranks over xGMI"""
+    parts = [partition(55, 50_000)]
+    img = image_of(parts)
+    t = ctx.open_image(img)
+    x = E.Exchange.rccl(ctx, 1, 0, E.Exchange.rccl_unique_id())
+    assert x.backend() == "rccl"
+    try:
+        for name in ("u64-key", "string-key", "two-keys", "high-card-leb-key"):
+            kw = dict(PLANS[name])
+            kc = kw.pop("key_cols", 1)
+            exp = O.oracle_run(img, Plan(S, **kw))
+            for mode in (K.EXCHANGE_GATHER_ALL, K.EXCHANGE_BY_OWNER):
+                q = t.query(Plan(S, **kw))
+                q.execute()
+                q.exchange(x, mode)
+                res = q.fetch_all()
+                assert res.nrows == exp.nrows
+                T.compare_results(res.rows(), exp.rows(), exp.types, key_cols=kc, rel=1e-9)
+                # a second execute + exchange of the same operator (bench.py's step)
+                q.execute()
+                q.exchange(x, mode)
+                assert q.fetch_all().nrows == exp.nrows
+                q.close()
+    finally:
+        x.close()
+        t.close()
