@@ -70,7 +70,13 @@ def config5w_plan():
                 scan_mode=K.SCAN_NESTED_WITHIN_RECORD, groups_hint=16)
 
 
-def cpu_baseline(ctx, plan_fn, columns, sample_rows, **gen_kw):
+REFERENCE_SQL = {
+    "config3": "select k, sum(a), count(1), sum(b) from t where a > 30000 and b < 30000 group by k;",
+    "config4": "select u, sum(a), count(1) from t where a >= 0 group by u;",
+}
+
+
+def cpu_baseline(ctx, plan_fn, columns, sample_rows, workload=None, **gen_kw):
     """the oracle (CPU restatement of the reference path, 1 thread) on a bounded
     sample of the same workload"""
     import oracle_lib as O
@@ -97,6 +103,29 @@ def cpu_baseline(ctx, plan_fn, columns, sample_rows, **gen_kw):
         out["all_cores"] = dict(value=T * sample_rows / dtp, unit="rows/s", cores=T,
                                 sample="%d threads, each the same %d-row partition, %.1f s"
                                        % (T, sample_rows, dtp))
+    # the REFERENCE's own engine where its build travelled here (oracle/_ref/csql_probe:
+    # csql::Runtime, parser, planner, VM, GroupByExpression over FastCSTableScan, compiled
+    # from the reference's sources by oracle/ref_csql/build.sh): timed on the same file.
+    # This snapshot of the reference has no sum(float64): its run uses the integer twin
+    # of the query (sum(a) for sum(v)).
+    probe = os.path.join(ROOT, "oracle", "_ref", "csql_probe")
+    ref_sql = REFERENCE_SQL.get(workload)
+    if os.path.exists(probe) and ref_sql:
+        import subprocess
+        cmds = "TABLE t %s fast\nROWS off\nTIME 1 %s\n" % (path, ref_sql)
+        try:
+            p = subprocess.run([probe], input=cmds, capture_output=True, text=True, timeout=600)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+            r = json.loads(line)
+            if r.get("ok"):
+                port = dict(out)
+                out = dict(value=sample_rows / r["seconds"], unit="rows/s", cores=1, kind="reference",
+                           sample="%d-row instance of the same table, the reference's own csql "
+                                  "engine (1 thread, as one partition runs): %s -- %d groups, %.1f s"
+                                  % (sample_rows, ref_sql, r["nrows"], r["seconds"]),
+                           port=port)
+        except Exception as e:  # the baseline is a reported figure, never a reason to fail
+            out["reference_error"] = str(e)[:200]
     os.unlink(path)
     return out
 
@@ -370,7 +399,8 @@ def main():
                                else "NO_AGGREGATION", res.nrows, dtc))
             else:
                 sample = args.cpu_sample_rows or (4_000_000 if high_card else 80_000_000)
-                out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample, **gen_kw)
+                out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample,
+                                                   workload=args.workload, **gen_kw)
         if world > 1:
             out["config"]["exchange_last_step"] = out_x
         if leb or string_keys:

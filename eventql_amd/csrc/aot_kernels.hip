@@ -1135,6 +1135,57 @@ __global__ void __launch_bounds__(kBlock) k_flatten_parent(const u8* leaf_levels
   }
 }
 
+// ---- CSTableScan's reset of parent values behind a rejected row (CSTableScan.cc:501-512)
+__global__ void __launch_bounds__(kBlock) k_level_tile_counts(const u8* levels, u32 thr, u64 n,
+                                                              u64* tile_counts) {
+  const u64 s0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 packed = *reinterpret_cast<const u64*>(levels + s0);
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += (((packed >> (8 * j)) & 0xff) <= thr && s0 + j < n) ? 1 : 0;
+  u32 total;
+  block_excl_scan(cnt, &total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock) k_slot_keep(const u8* levels, const u64* tile_offsets,
+                                                      u32 thr, u64 n, const u8* acc, u8* slot_keep) {
+  const u64 s0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 packed = *reinterpret_cast<const u64*>(levels + s0);
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += (((packed >> (8 * j)) & 0xff) <= thr && s0 + j < n) ? 1 : 0;
+  u32 total;
+  u64 idx = tile_offsets[blockIdx.x] + block_excl_scan(cnt, &total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (((packed >> (8 * j)) & 0xff) <= thr && s0 + j < n) slot_keep[idx++] = acc[s0 + j];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_mask_parent(const u8* levels, const u64* tile_offsets,
+                                                        u32 thr, u64 n, const u8* slot_keep,
+                                                        const u64* in, u64* out) {
+  const u64 s0 = (u64) blockIdx.x * kDecodeTile + (u64) threadIdx.x * 8;
+  const u64 packed = *reinterpret_cast<const u64*>(levels + s0);
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += (((packed >> (8 * j)) & 0xff) <= thr && s0 + j < n) ? 1 : 0;
+  u32 total;
+  u64 idx = tile_offsets[blockIdx.x] + block_excl_scan(cnt, &total);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u64 s = s0 + j;
+    const bool first = ((packed >> (8 * j)) & 0xff) <= thr && s < n;
+    if (first) ++idx;
+    // the first row of a slot reads the freshly fetched value; the rows behind it read
+    // it only if that first row passed the WHERE
+    u64 v = 0;
+    if (s < n) v = (first || (idx > 0 && slot_keep[idx - 1])) ? in[s] : 0;
+    out[s] = v;
+  }
+}
+
 // AGGREGATE_WITHIN_RECORD_FLAT: every thread walks a window of 8 consecutive
 // flattened rows (rows of one record are adjacent).  Records inside one window
 // are summed in registers and stored plainly.  A record that spans windows is
@@ -1489,6 +1540,34 @@ hipError_t launch_flatten_parent(const uint8_t* leaf_levels, const uint64_t* til
   if (ntiles == 0) return hipSuccess;
   hipLaunchKernelGGL(k_flatten_parent, dim3((unsigned) ntiles), dim3(kBlock), 0, s, leaf_levels,
                      (const u64*) tile_offsets, thr, (u64) nflat, (const u64*) vals, (u64*) flat);
+  return hipGetLastError();
+}
+
+hipError_t launch_level_tile_counts(const uint8_t* levels, uint32_t thr, uint64_t n,
+                                    uint64_t* tile_counts, hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_level_tile_counts, dim3((unsigned) ntiles), dim3(kBlock), 0, s, levels, thr,
+                     (u64) n, (u64*) tile_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_slot_keep(const uint8_t* levels, const uint64_t* tile_offsets, uint32_t thr,
+                            uint64_t n, const uint8_t* acc, uint8_t* slot_keep, hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_slot_keep, dim3((unsigned) ntiles), dim3(kBlock), 0, s, levels,
+                     (const u64*) tile_offsets, thr, (u64) n, acc, slot_keep);
+  return hipGetLastError();
+}
+
+hipError_t launch_mask_parent(const uint8_t* levels, const uint64_t* tile_offsets, uint32_t thr,
+                              uint64_t n, const uint8_t* slot_keep, const uint64_t* in,
+                              uint64_t* out, hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_mask_parent, dim3((unsigned) ntiles), dim3(kBlock), 0, s, levels,
+                     (const u64*) tile_offsets, thr, (u64) n, slot_keep, (const u64*) in, (u64*) out);
   return hipGetLastError();
 }
 

@@ -2,6 +2,8 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <chrono>
+#include <thread>
 #include "runtime.h"
 #include "sha1.h"
 
@@ -551,9 +553,26 @@ int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user) {
   if (hb && hb(user) != 0) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
   Status st = query_launch(q);
   if (!st.ok()) return ret(st);
+  // GroupByExpression::execute calls txn_->triggerHeartbeat() once per input batch
+  // (groupby.cc:100-105) so that a long scan keeps its connection alive; here the scan
+  // is a kernel in flight: the host polls the stream and beats every 5 ms meanwhile.
+  // A heartbeat that asks to stop is honoured once the kernels have drained (a running
+  // grid is not cancelled).
+  bool aborted = false;
+  if (hb) {
+    auto last = std::chrono::steady_clock::now();
+    while (hipStreamQuery(q->ctx->stream) == hipErrorNotReady) {
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+      const auto now = std::chrono::steady_clock::now();
+      if (now - last >= std::chrono::milliseconds(5)) {
+        last = now;
+        if (hb(user) != 0) aborted = true;
+      }
+    }
+  }
   st = query_finish(q);
   if (!st.ok()) return ret(st);
-  if (hb && hb(user) != 0) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
+  if (aborted || (hb && hb(user) != 0)) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
   return EVQL_OK;
   API_CATCH
 }

@@ -74,6 +74,10 @@ struct KernelPlan {
   // of tuples, then aggregate each bucket in LDS (codegen_kernels.inc)
   bool partitioned = false;
   int part_bits = 12;
+  // nested scans whose WHERE reads columns of different repetition depth: an extra
+  // kernel (evql_where_rows) writes the predicate of every row, from which the runtime
+  // reproduces the reference's reset of parent values behind a rejected row
+  bool where_rows_kernel = false;
   int tile_rows() const { return block * 2 * unroll; }
 };
 

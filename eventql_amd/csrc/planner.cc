@@ -344,7 +344,11 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
       hi = rm > hi ? rm : hi;
     }
     if (!kp.cols.empty() && lo != hi) {
-      return unsup("WHERE over columns of different repetition depth in a nested scan");
+      // reproduced by the runtime (apply_where_resets): a parent value reads 0 behind
+      // the first row of its slot when that row was rejected
+      if (within) return unsup("WHERE over columns of different repetition depth in a record scan");
+      kp.where_rows_kernel = true;
+      q->nested_where_mixed = true;
     }
   }
 

@@ -113,6 +113,9 @@ Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out, boo
         HIP_TRY(hipModuleGetFunction(&out->fn_refine, out->mod, "evql_part_refine"));
       }
     }
+    if (source.find("evql_where_rows") != std::string::npos) {
+      HIP_TRY(hipModuleGetFunction(&out->fn_where, out->mod, "evql_where_rows"));
+    }
     if (ctx) ctx->modules[key] = *out;
   }
   return Status();
@@ -1023,13 +1026,17 @@ static uint64_t word_identity(int op) {
 
 static Status compile_plan_kernels(evql_query* q);
 
+static Status apply_where_resets(evql_query* q, const evql_table::LeafLevels& leaf);
+
 Status query_prepare(evql_query* q) {
   evql_table* t = q->table;
+  evql_table::LeafLevels where_leaf;
   if (q->within_record) {
     Status st = materialize_within_record(q);
     if (!st.ok()) return st;
   } else if (q->nested) {
-    Status st = materialize_nested(q, q->kp.cols, &q->nested_flat, &q->nested_rows, nullptr);
+    Status st = materialize_nested(q, q->kp.cols, &q->nested_flat, &q->nested_rows,
+                                   q->nested_where_mixed ? &where_leaf : nullptr);
     if (!st.ok()) return st;
   }
   // resolve bit widths and materialise SoA columns
@@ -1063,6 +1070,10 @@ Status query_prepare(evql_query* q) {
   if (!st.ok()) return st;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_status), 16));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_counters), 64));
+  if (q->nested_where_mixed) {
+    st = apply_where_resets(q, where_leaf);
+    if (!st.ok()) return st;
+  }
   HIP_TRY(hipEventCreate(&q->ev0));
   HIP_TRY(hipEventCreate(&q->ev1));
   if (!q->row_filter_host.empty()) {
@@ -1159,9 +1170,126 @@ static Status probe_cardinality(evql_query* q) {
   return Status();
 }
 
+// the kernel arguments that do not change between launches of one operator
+static void fill_host_args(evql_query* q, HostArgs* ap) {
+  HostArgs& a = *ap;
+  evql_table* t = q->table;
+  const KernelPlan& kp = q->kp;
+  a.image = t->d_image;
+  const uint64_t nrows = q->nested ? q->nested_rows : t->layout.num_rows;
+  a.row_begin = std::min(q->row_begin, nrows);
+  a.row_end = q->row_end ? std::min(q->row_end, nrows) : nrows;
+  const uint64_t T = uint64_t(kp.tile_rows());
+  a.tile0 = a.row_begin / T;
+  a.ntiles = a.row_end > a.row_begin ? (a.row_end + T - 1) / T - a.tile0 : 0;
+  a.row_filter = q->d_row_filter;
+  a.row_filter_len = q->row_filter_len;
+  a.gtab = q->d_gtab;
+  a.gcap = q->gcap;
+  a.status = q->d_status;
+  a.counters = q->d_counters;
+  for (size_t i = 0; i < kp.cols.size(); ++i) {
+    const ColAccess& c = kp.cols[i];
+    a.col[i].base = t->d_image;
+    if (c.layout_index >= 0) {
+      a.col[i].pages = t->d_pages[c.layout_index][0];
+      a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
+    }
+    if (c.packed) {
+      const MaterializedColumn& m = t->materialized[c.name];
+      a.col[i].pages = m.d_packed_pages;
+      a.col[i].base = m.d_packed;
+    }
+    if (q->nested) {
+      a.col[i].soa = q->nested_flat[i];
+    } else if (c.mode == ColAccess::SOA) {
+      const MaterializedColumn& m = t->materialized[c.name];
+      a.col[i].soa = m.d_values;
+      a.col[i].tags = m.d_tags;
+      a.col[i].strpos = m.d_strpos;
+    }
+  }
+}
+
+// CSTableScan::fetchNext keeps the values of shallower columns across the rows of one
+// slot, but after a row that WHERE rejects it resets every column at or below the
+// running select level without re-reading it (CSTableScan.cc:501-512).  Worked out per
+// column C of repetition depth c: the rows of a slot of C read C's value, except that
+// they read 0 from the second row on when the slot's FIRST row was rejected (the first
+// row itself always sees the freshly fetched value).  Whether a first row is rejected
+// depends only on fresh values and on columns shallower than c, so the depths are
+// settled one after the other, shallowest first: predicate of every row over the
+// columns as they stand (evql_where_rows), verdict of every slot's first row
+// (k_slot_keep), masked copy of the depth's columns (k_mask_parent).  Pinned by the
+// reference's own engine on tests/golden/ref_csql_nested.json.
+static Status apply_where_resets(evql_query* q, const LeafLevels& leaf) {
+  evql_table* t = q->table;
+  hipStream_t s = q->ctx->stream;
+  const KernelPlan& kp = q->kp;
+  const uint64_t n = q->nested_rows;
+  if (n == 0 || !leaf.levels || !q->module.fn_where) return Status();
+  uint32_t leaf_depth = 0;
+  std::vector<uint32_t> depths;
+  for (const auto& c : kp.cols) {
+    leaf_depth = std::max(leaf_depth, t->layout.columns[c.layout_index].rlevel_max);
+  }
+  for (const auto& c : kp.cols) {
+    const uint32_t d = t->layout.columns[c.layout_index].rlevel_max;
+    if (d < leaf_depth && std::find(depths.begin(), depths.end(), d) == depths.end()) depths.push_back(d);
+  }
+  std::sort(depths.begin(), depths.end());
+  const uint64_t np = padded_rows(n);
+  const uint64_t ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  DevBuf<uint8_t> d_acc, d_keep;
+  DevBuf<uint64_t> d_off;
+  HIP_TRY(d_acc.alloc(np));
+  HIP_TRY(d_keep.alloc(np));
+  HIP_TRY(d_off.alloc((ntiles + 2) * 8));
+  HIP_TRY(hipMemsetAsync(d_acc, 0, np, s));
+  struct WhereArgs {
+    HostArgs a;
+    uint8_t* acc;
+  };
+  for (uint32_t d : depths) {
+    WhereArgs wa{};
+    fill_host_args(q, &wa.a);
+    wa.acc = d_acc;
+    size_t sz = sizeof(WhereArgs);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &wa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                      HIP_LAUNCH_PARAM_END};
+    int grid = q->grid;
+    if (uint64_t(grid) > wa.a.ntiles) grid = int(wa.a.ntiles);
+    if (grid > 0) {
+      HIP_TRY(hipModuleLaunchKernel(q->module.fn_where, grid, 1, 1, kp.block, 1, 1, 0, s, nullptr,
+                                    config));
+    }
+    HIP_TRY(launch_level_tile_counts(leaf.levels, d, n, d_off, s));
+    HIP_TRY(launch_exclusive_scan(d_off, ntiles, nullptr, s));
+    HIP_TRY(hipMemsetAsync(d_keep, 0, np, s));
+    HIP_TRY(launch_slot_keep(leaf.levels, d_off, d, n, d_acc, d_keep, s));
+    std::map<uint64_t*, uint64_t*> done;  // (a column referenced twice shares one buffer)
+    for (size_t i = 0; i < kp.cols.size(); ++i) {
+      if (t->layout.columns[kp.cols[i].layout_index].rlevel_max != d) continue;
+      auto hit = done.find(q->nested_flat[i]);
+      if (hit != done.end()) {
+        q->nested_flat[i] = hit->second;
+        continue;
+      }
+      DevBuf<uint64_t> d_out;
+      HIP_TRY(d_out.alloc(np * 8));
+      HIP_TRY(hipMemsetAsync(d_out, 0, np * 8, s));
+      HIP_TRY(launch_mask_parent(leaf.levels, d_off, d, n, d_keep, q->nested_flat[i], d_out, s));
+      done[q->nested_flat[i]] = d_out;
+      q->nested_flat[i] = d_out;
+      q->nested_owned.push_back(d_out.release());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return Status();
+}
+
 Status query_launch(evql_query* q) {
   evql_ctx* ctx = q->ctx;
-  evql_table* t = q->table;
   if (!q->probed && q->groups_hint == 0 && q->kp.key_mode != KEY_NONE && !q->within_record) {
     q->probed = true;
     Status st = probe_cardinality(q);
@@ -1200,40 +1328,7 @@ Status query_launch(evql_query* q) {
   HIP_TRY(hipMemsetAsync(q->d_counters, 0, 64, s));
 
   HostArgs a{};
-  a.image = t->d_image;
-  const uint64_t nrows = q->nested ? q->nested_rows : t->layout.num_rows;
-  a.row_begin = std::min(q->row_begin, nrows);
-  a.row_end = q->row_end ? std::min(q->row_end, nrows) : nrows;
-  const uint64_t T = uint64_t(kp.tile_rows());
-  a.tile0 = a.row_begin / T;
-  a.ntiles = a.row_end > a.row_begin ? (a.row_end + T - 1) / T - a.tile0 : 0;
-  a.row_filter = q->d_row_filter;
-  a.row_filter_len = q->row_filter_len;
-  a.gtab = q->d_gtab;
-  a.gcap = q->gcap;
-  a.status = q->d_status;
-  a.counters = q->d_counters;
-  for (size_t i = 0; i < kp.cols.size(); ++i) {
-    const ColAccess& c = kp.cols[i];
-    a.col[i].base = t->d_image;
-    if (c.layout_index >= 0) {
-      a.col[i].pages = t->d_pages[c.layout_index][0];
-      a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
-    }
-    if (c.packed) {
-      const MaterializedColumn& m = t->materialized[c.name];
-      a.col[i].pages = m.d_packed_pages;
-      a.col[i].base = m.d_packed;
-    }
-    if (q->nested) {
-      a.col[i].soa = q->nested_flat[i];
-    } else if (c.mode == ColAccess::SOA) {
-      const MaterializedColumn& m = t->materialized[c.name];
-      a.col[i].soa = m.d_values;
-      a.col[i].tags = m.d_tags;
-      a.col[i].strpos = m.d_strpos;
-    }
-  }
+  fill_host_args(q, &a);
   if (kp.n_distinct > 0) {
     // count_distinct pair sets: emptied before every launch
     if (q->pairset_cap == 0) {

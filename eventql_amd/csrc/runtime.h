@@ -56,6 +56,7 @@ struct Module {
   // partitioned high-cardinality path (present only when the plan asks for it)
   hipFunction_t fn_count = nullptr, fn_scatter = nullptr, fn_aggregate = nullptr;
   hipFunction_t fn_refine = nullptr;  // second scatter level (part_bits > 8)
+  hipFunction_t fn_where = nullptr;   // evql_where_rows (nested scans, mixed-depth WHERE)
   size_t code_size = 0;
 };
 
@@ -222,6 +223,7 @@ struct evql_query {
   uint64_t nested_rows = 0;
   std::vector<uint64_t*> nested_flat;
   std::vector<uint64_t*> nested_owned;
+  bool nested_where_mixed = false;  // WHERE over columns of different repetition depth
   // EVQL_SCAN_NESTED_WITHIN_RECORD (CSTableScan.cc:440-487,
   // AGGREGATE_WITHIN_RECORD_FLAT): the scan select list holds one aggregate per
   // expression, reduced to one value per record; those per-record arrays are

@@ -419,7 +419,10 @@ void evql_query_destroy(evql_query_t* q);
 typedef int (*evql_heartbeat_fn)(void* user);
 
 /* TableExpression::execute (table_expression.h:38): runs scan+filter+aggregate
- * to completion on the device. */
+ * to completion on the device.  `hb` is called before the launch, every 5 ms while the
+ * kernels run (the host polls the stream) and once after them -- the reference beats
+ * once per input batch (groupby.cc:100-105); non-zero = stop: honoured when the
+ * kernels have drained, execute then fails with EVQL_ERUNTIME "query aborted". */
 int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user);
 
 /* asynchronous form used by benchmarks: enqueue the kernels on the context

@@ -51,11 +51,27 @@ class RefGen(Gen):
 
 class RefNestedGen(NestedGen, RefGen):
     aggregate = RefGen.aggregate
+    schema = None
 
     def plan_kwargs(self, row_ends):
         kw = NestedGen.plan_kwargs(self, row_ends)
         kw.pop("row_end", None)
         kw.pop("row_filter", None)
+        if "where" not in kw and self.r.random() < 0.7:
+            # a predicate over columns of DIFFERENT repetition depth: after a rejected
+            # row the reference resets parent values without re-reading them
+            # (CSTableScan.cc:501-512).  Only over columns the plan selects anyway, so
+            # that the scan stays in its well-defined regime (sqlgen.make_runnable)
+            used = []
+            for e in kw["group_by"] + kw["select"]:
+                sqlgen._columns(e, used)
+            u = [c for c in used if self.schema[c] == K.T_UINT64]
+            b = [c for c in used if self.schema[c] == K.T_BOOL]
+            if u:
+                g2 = RefGen(self.r.randrange(1 << 30), uint_cols=u, float_cols=[], bool_cols=b,
+                            key_cols=u, first_cols=u, lits=self.lits)
+                g2.flt = lambda depth=0: Lit(g2.r.choice([0.0, 1.5, 100.0]))
+                kw["where"] = g2.boolean()
         return kw
 
 
@@ -207,11 +223,12 @@ def nested_cases():
     """CSTableScan (Dremel assembly), AggregationStrategy::NO_AGGREGATION"""
     import nested_tables as N
     out = []
-    for seed in range(80):
+    for seed in range(120):
         which = seed % 2
         table, schema, cols = (("items", N.ITEMS_SCHEMA, ITEMS) if which == 0 else
                                ("testtbl", N.NESTED_SCHEMA, TESTTBL))
         g = RefNestedGen(70_000 + seed, **cols)
+        g.schema = schema
         g.count_cols = list(cols["uint_cols"]) + list(cols["bool_cols"])
         if which == 0:
             g.leaf_uint, g.leaf_bool = ["items.position", "items.price"], []
