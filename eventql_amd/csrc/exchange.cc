@@ -232,7 +232,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
       rc[c].bits = ca.bits;
       if (q->nested) {
         rc[c].mode = ColAccess::SOA;
-        rc[c].soa = q->nested_flat[c];
+        rc[c].soa = ca.string_hash ? q->nested_strpos[c] : q->nested_flat[c];
       } else if (ca.packed) {
         const MaterializedColumn& m = t->materialized[ca.name];
         rc[c].pages = m.d_packed_pages;

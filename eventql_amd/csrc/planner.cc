@@ -282,7 +282,8 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     if (nested) {
       // CSTableScan path: every column is flattened to one value per output row;
       // undefined slots read as 0 with tag 0 (CSTableScan.cc:224-246)
-      if (c.string_hash) return unsup("string columns in nested scans are not lowered yet");
+      // (strings: hash + byte position per flattened row, materialize_nested)
+      if (c.string_hash && within) return unsup("string columns in a record scan are not lowered");
       c.mode = ColAccess::SOA;
       c.has_tags = false;
     }

@@ -234,6 +234,7 @@ evql_table::~evql_table() {
   // (`materialized` columns free their device arrays themselves)
   for (auto& kv : nested_cache) {
     if (kv.second.d_values) hipFree(kv.second.d_values);
+    if (kv.second.d_hash) hipFree(kv.second.d_hash);
   }
   for (auto& kv : leaf_cache) {
     if (kv.second.levels) hipFree(kv.second.levels);
@@ -715,6 +716,15 @@ static Status nested_slot_values(evql_table* t, int li, uint64_t nslots_flat, ui
       src.soa = d_dense;
       break;
     }
+    case ColumnEncoding::STRING_PLAIN: {
+      // a string slot's "value" is where its bytes are: (len << 40) | position
+      HIP_TRY(d_dense.alloc(std::max<uint64_t>(nvalues, 1) * 8));
+      Status st = locate_string_values(t, c, li, nvalues, d_dense);
+      if (!st.ok()) return st;
+      src.mode = ColAccess::SOA;
+      src.soa = d_dense;
+      break;
+    }
     default:
       return Status::error(EVQL_ENOTSUP, "unsupported nested column encoding");
   }
@@ -777,7 +787,7 @@ static Status exact_slot_count(evql_table* t, int li, uint64_t* out) {
 // (*flat)[i] is borrowed from the table's nested cache
 static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& cols,
                                  std::vector<uint64_t*>* flat_out, uint64_t* nrows_out,
-                                 LeafLevels* keep) {
+                                 LeafLevels* keep, std::vector<uint64_t*>* strpos_out = nullptr) {
   evql_table* t = q->table;
   evql_ctx* ctx = q->ctx;
   hipStream_t s = ctx->stream;
@@ -787,6 +797,17 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
   std::vector<uint64_t*>& nested_flat = *flat_out;
   const uint64_t nrec = t->layout.num_rows;
   nested_flat.assign(kp.cols.size(), nullptr);
+  if (strpos_out) strpos_out->assign(kp.cols.size(), nullptr);
+  // a string column's row value is (len << 40 | position); the kernels group and
+  // compare on its hash (`flat`) and read the bytes through the position (`strpos`)
+  auto publish = [&](size_t i, const evql_table::NestedFlat& e) {
+    if (kp.cols[i].string_hash) {
+      nested_flat[i] = e.d_hash;
+      if (strpos_out) (*strpos_out)[i] = e.d_values;
+    } else {
+      nested_flat[i] = e.d_values;
+    }
+  };
   if (kp.cols.empty()) {
     *nrows_out = nrec;  // fetchNextWithoutColumns: one row per record
     return Status();
@@ -809,7 +830,7 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
       if (keep && lc.rlevel_max > 0) *keep = t->leaf_cache[leaf_li];
       for (size_t i = 0; i < kp.cols.size(); ++i) {
         const auto& e = t->nested_cache[{kp.cols[i].layout_index, leaf_li}];
-        nested_flat[i] = e.d_values;
+        publish(i, e);
         *nrows_out = e.nflat;
       }
       return Status();
@@ -881,19 +902,12 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
   const uint64_t flatp = padded_rows(nflat);
   for (size_t i = 0; i < kp.cols.size(); ++i) {
     // the same column referenced twice shares one buffer
-    bool shared = false;
-    for (size_t j = 0; j < i; ++j) {
-      if (kp.cols[j].layout_index == kp.cols[i].layout_index) {
-        nested_flat[i] = nested_flat[j];
-        shared = true;
-      }
-    }
-    if (shared) continue;
     const int li = kp.cols[i].layout_index;
     {
+      // (the same column referenced twice, or flattened by an earlier operator)
       auto hit = t->nested_cache.find({li, leaf_li});
       if (hit != t->nested_cache.end()) {
-        nested_flat[i] = hit->second.d_values;
+        publish(i, hit->second);
         continue;
       }
     }
@@ -936,8 +950,7 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
         // level streams shorter than the leaf's: not the same ancestor chain
         return Status::error(EVQL_ENOTSUP, "nested columns from different repeated groups");
       }
-      nested_flat[i] = d_vals;
-      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_vals.release(), nflat};
+      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_vals.release(), nflat, nullptr};
     } else {
       size_t k = 0;
       while (thr_levels[k] != c.rlevel_max) ++k;
@@ -947,9 +960,18 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
       HIP_TRY(launch_flatten_parent(leaf_levels, thr_offsets[k], c.rlevel_max, nflat, d_vals,
                                     d_flat, s));
       HIP_TRY(hipStreamSynchronize(s));
-      nested_flat[i] = d_flat;
-      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_flat.release(), nflat};
+      t->nested_cache[{li, leaf_li}] = evql_table::NestedFlat{d_flat.release(), nflat, nullptr};
     }
+    evql_table::NestedFlat& e = t->nested_cache[{li, leaf_li}];
+    if (kp.cols[i].string_hash) {
+      // undefined slots carry strpos 0: the empty string (an all-zero SValue read as
+      // a STRING, CSTableScan.cc:224-246)
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e.d_hash), flatp * 8));
+      HIP_TRY(hipMemsetAsync(e.d_hash, 0, flatp * 8, s));
+      HIP_TRY(launch_string_hash(t->d_image, t->d_pages[li][0], e.d_values, nflat, e.d_hash, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    publish(i, e);
   }
   if (keep && lc.rlevel_max > 0) {
     auto hit = t->leaf_cache.find(leaf_li);
@@ -1036,7 +1058,8 @@ Status query_prepare(evql_query* q) {
     if (!st.ok()) return st;
   } else if (q->nested) {
     Status st = materialize_nested(q, q->kp.cols, &q->nested_flat, &q->nested_rows,
-                                   q->nested_where_mixed ? &where_leaf : nullptr);
+                                   q->nested_where_mixed ? &where_leaf : nullptr,
+                                   &q->nested_strpos);
     if (!st.ok()) return st;
   }
   // resolve bit widths and materialise SoA columns
@@ -1202,6 +1225,7 @@ static void fill_host_args(evql_query* q, HostArgs* ap) {
     }
     if (q->nested) {
       a.col[i].soa = q->nested_flat[i];
+      if (i < q->nested_strpos.size()) a.col[i].strpos = q->nested_strpos[i];
     } else if (c.mode == ColAccess::SOA) {
       const MaterializedColumn& m = t->materialized[c.name];
       a.col[i].soa = m.d_values;
@@ -1278,7 +1302,19 @@ static Status apply_where_resets(evql_query* q, const LeafLevels& leaf) {
       DevBuf<uint64_t> d_out;
       HIP_TRY(d_out.alloc(np * 8));
       HIP_TRY(hipMemsetAsync(d_out, 0, np * 8, s));
-      HIP_TRY(launch_mask_parent(leaf.levels, d_off, d, n, d_keep, q->nested_flat[i], d_out, s));
+      if (kp.cols[i].string_hash) {
+        // a reset string reads "" (an all-zero SValue): mask the positions, hash again
+        DevBuf<uint64_t> d_sp;
+        HIP_TRY(d_sp.alloc(np * 8));
+        HIP_TRY(hipMemsetAsync(d_sp, 0, np * 8, s));
+        HIP_TRY(launch_mask_parent(leaf.levels, d_off, d, n, d_keep, q->nested_strpos[i], d_sp, s));
+        HIP_TRY(launch_string_hash(t->d_image, t->d_pages[kp.cols[i].layout_index][0], d_sp, n,
+                                   d_out, s));
+        q->nested_strpos[i] = d_sp;
+        q->nested_owned.push_back(d_sp.release());
+      } else {
+        HIP_TRY(launch_mask_parent(leaf.levels, d_off, d, n, d_keep, q->nested_flat[i], d_out, s));
+      }
       done[q->nested_flat[i]] = d_out;
       q->nested_flat[i] = d_out;
       q->nested_owned.push_back(d_out.release());
@@ -1780,7 +1816,7 @@ static Status fetch_results(evql_query* q) {
         rc[c].base = m.d_packed;
       }
       if (q->nested) {
-        rc[c].soa = q->nested_flat[c];
+        rc[c].soa = ca.string_hash ? q->nested_strpos[c] : q->nested_flat[c];
       } else if (ca.mode == ColAccess::SOA) {
         const MaterializedColumn& m = t->materialized[ca.name];
         // strings: (len << 40 | position); their bytes are copied out below

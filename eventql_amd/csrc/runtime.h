@@ -165,8 +165,9 @@ struct evql_table {
   // deepest repeated column is `leaf` -- key (column, leaf) layout indices.  Like
   // `materialized`, decoded once per table and shared by every operator.
   struct NestedFlat {
-    uint64_t* d_values = nullptr;
+    uint64_t* d_values = nullptr;  // per row: value bits; strings: (len << 40 | position)
     uint64_t nflat = 0;
+    uint64_t* d_hash = nullptr;    // strings: 64-bit hash of the row's bytes
   };
   std::map<std::pair<int, int>, NestedFlat> nested_cache;
   // record scans (WITHIN RECORD): the leaf's decoded repetition levels (one byte
@@ -222,6 +223,7 @@ struct evql_query {
   bool nested = false;
   uint64_t nested_rows = 0;
   std::vector<uint64_t*> nested_flat;
+  std::vector<uint64_t*> nested_strpos;  // string columns: (len << 40 | position) per row
   std::vector<uint64_t*> nested_owned;
   bool nested_where_mixed = false;  // WHERE over columns of different repetition depth
   // EVQL_SCAN_NESTED_WITHIN_RECORD (CSTableScan.cc:440-487,

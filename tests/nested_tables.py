@@ -15,6 +15,10 @@ NESTED_COLS = [
     ("event.search_query.num_result_items", K.COL_UNSIGNED_INT, K.ENC_UINT32_BITPACKED),
     ("event.search_query.result_items.position", K.COL_UNSIGNED_INT, K.ENC_UINT32_PLAIN),
     ("event.search_query.result_items.clicked", K.COL_BOOLEAN, K.ENC_BOOLEAN_BITPACKED),
+    # string fields at every repetition depth
+    ("session_id", K.COL_STRING, K.ENC_STRING_PLAIN),
+    ("event.search_query.query_string", K.COL_STRING, K.ENC_STRING_PLAIN),
+    ("event.search_query.result_items.item_id", K.COL_STRING, K.ENC_STRING_PLAIN),
 ]
 
 NESTED_SCHEMA = {
@@ -23,6 +27,9 @@ NESTED_SCHEMA = {
     "event.search_query.num_result_items": K.T_UINT64,
     "event.search_query.result_items.position": K.T_UINT64,
     "event.search_query.result_items.clicked": K.T_BOOL,
+    "session_id": K.T_STRING,
+    "event.search_query.query_string": K.T_STRING,
+    "event.search_query.result_items.item_id": K.T_STRING,
 }
 
 
@@ -40,7 +47,7 @@ def testtbl_v2():
         specs.append(dict(name=name, logical_type=lt, storage_type=enc,
                           rlevel_max=ci["rlevel_max"], dlevel_max=ci["dlevel_max"]))
         nvals = L.orc_table_column_num_values(r.h, name.encode())
-        data[name] = r.read(name, nvals, "uint")
+        data[name] = r.read(name, nvals, "string" if lt == K.COL_STRING else "uint")
     r.close()
     w = E.Writer(specs)
     for name, _, _ in NESTED_COLS:

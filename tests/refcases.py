@@ -213,8 +213,12 @@ TESTTBL = dict(uint_cols=["time", "event.search_query.time",
                float_cols=[], bool_cols=["event.search_query.result_items.clicked"],
                key_cols=["event.search_query.result_items.position",
                          "event.search_query.num_result_items",
-                         "event.search_query.result_items.clicked"],
-               first_cols=["time", "event.search_query.num_result_items"],
+                         "event.search_query.result_items.clicked",
+                         # string fields of every repetition depth (0, 1, 2)
+                         "session_id", "event.search_query.query_string",
+                         "event.search_query.result_items.item_id"],
+               first_cols=["time", "event.search_query.num_result_items",
+                           "event.search_query.query_string", "session_id"],
                lits=[0, 1, 2, 6, 10, 1438055327])
 
 

@@ -590,11 +590,18 @@ def test_nested_scan_known_answers(ctx):
         T.compare_results(got.rows(), exp.rows(), exp.types, key_cols=len(kw.get("group_by", [])))
         assert q.stats()["rows_passed"] == exp.rows_passed
         q.close()
-    # not lowerable: WHERE mixing repetition depths (the reference's reset quirk)
-    with pytest.raises(E.EvqlError) as ei:
-        t.query(Plan(S, select=[count(1)], where=(pos > 3) & (nitems > 10),
-                     scan_mode=K.SCAN_NESTED))
-    assert ei.value.code == K.EVQL_ENOTSUP
+    # WHERE mixing repetition depths: after a rejected row the reference resets parent
+    # values without re-reading them (CSTableScan.cc:501-512) -- reproduced; the
+    # reference-generated cases are in test_gpu_ref_csql.py
+    for where in ((pos > 3) & (nitems > 10), (nitems > 10) | (pos < 2),
+                  ~(col("time") > 1438055327000000) | (pos > 7)):
+        plan = Plan(S, select=[nitems, count(1), sum_(pos), sum_(col("time"))], group_by=[nitems],
+                    where=where, scan_mode=K.SCAN_NESTED)
+        exp = O.oracle_run(img, plan)
+        q = t.query(plan)
+        assert "evql_where_rows" in q.kernel_source()
+        T.compare_results(q.run().rows(), exp.rows(), exp.types, key_cols=1)
+        q.close()
     t.close()
 
 
