@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--no-hint", action="store_true",
                     help="plans without groups_hint (the reference's planner has none): the "
                          "first execute estimates the cardinality itself")
+    ap.add_argument("--float-sums", default="fast", choices=["fast", "exact"],
+                    help="exact: EVQL_FLOAT_SUM_EXACT (order-independent, bit-stable float sums)")
     ap.add_argument("--k-bits", type=int, default=0,
                     help="config2 run B (SURVEY.md 8d): k as UINT32_BITPACKED of this width")
     args = ap.parse_args()
@@ -182,7 +184,10 @@ def main():
                          (100_000_000 if nested or args.workload == "config3l" else 1_000_000_000))
     if args.scaling == "strong":
         rows = rows // world  # the job's rows are fixed, every rank scans its share
-    plan_fn = {"config2": B.config2, "config3": B.config3, "config3l": B.config3,
+    fs = dict(float_sum_mode=K.FLOAT_SUM_EXACT) if args.float_sums == "exact" else {}
+    plan_fn = {"config2": lambda **kw: B.config2(**fs, **kw),
+               "config3": lambda **kw: B.config3(**fs, **kw),
+               "config3l": lambda **kw: B.config3(**fs, **kw),
                "config5": config5_plan, "config5w": config5w_plan,
                "config4": lambda **kw: B.config4(groups_hint=0 if args.no_hint else n_keys, **kw),
                "config4s": lambda **kw: B.config4s(groups_hint=0 if args.no_hint else n_keys, **kw)
@@ -356,6 +361,7 @@ def main():
                 "partitions": world,
                 "merge": merge,
                 "groups_hint": "none (estimated by the first execute)" if args.no_hint else "given",
+                "float_sums": args.float_sums,
             },
             "roofline": {
                 "bound": "hbm",

@@ -93,6 +93,8 @@ class PlanDesc(C.Structure):
         ("groups_hint", C.c_uint64),
         ("row_begin", C.c_uint64),
         ("row_end", C.c_uint64),
+        ("float_sum_mode", C.c_uint32),
+        ("float_sum_bound", C.c_double),
     ]
 
 
@@ -191,3 +193,6 @@ ALL_TO_ALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint6
 class Transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_gather_u64", ALL_GATHER_FN),
                 ("all_to_all_words", ALL_TO_ALL_FN), ("name", C.c_char_p)]
+
+FLOAT_SUM_FAST = 0
+FLOAT_SUM_EXACT = 1

@@ -484,6 +484,24 @@ __global__ void k_string_hash(const u8* image, const u64* pages, const u64* strp
   }
 }
 
+__global__ void __launch_bounds__(kBlock) k_column_abs_max(const u8* image, RtColumn col, u64 n,
+                                                           u32 is_float, u64* out) {
+  u64 m = 0;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    u64 v = rt_column_value(image, col, i);
+    if (is_float) v &= 0x7fffffffffffffffull;  // fabs
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    u32 lo = __shfl_xor((u32) m, d, 64), hi = __shfl_xor((u32) (m >> 32), d, 64);
+    const u64 o = (u64) lo | ((u64) hi << 32);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax((unsigned long long*) out, (unsigned long long) m);
+}
+
 __global__ void __launch_bounds__(kBlock) k_max_u64(const u64* values, u64 n, u64* out) {
   u64 m = 0;
   for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1457,6 +1475,14 @@ hipError_t launch_table_merge_resolved(const MergeResolvedArgs& a, const uint64_
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_table_merge_resolved, dim3(grid_for(n)), dim3(kBlock), 0, s, a,
                      (const u64*) records, (u64) n);
+  return hipGetLastError();
+}
+
+hipError_t launch_column_abs_max(const uint8_t* image, const RtColumn& col, uint64_t n,
+                                 uint32_t is_float, uint64_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_column_abs_max, dim3(grid_for(n, kBlock, 4096)), dim3(kBlock), 0, s, image,
+                     col, (u64) n, is_float, (u64*) out);
   return hipGetLastError();
 }
 

@@ -514,6 +514,11 @@ int evql_query_create(evql_ctx_t* ctx, evql_table_t* table, const evql_plan_desc
   q->table = table;
   q->group_mode = plan->group_mode;
   q->groups_hint = plan->groups_hint;
+  q->float_sum_mode = plan->float_sum_mode;
+  q->float_sum_bound = plan->float_sum_bound;
+  if (plan->float_sum_mode > EVQL_FLOAT_SUM_EXACT || !(plan->float_sum_bound >= 0)) {
+    return fail(EVQL_EARG, "bad float sum mode / bound");
+  }
   q->row_begin = plan->row_begin;
   q->row_end = plan->row_end;
   if (plan->group_mode != EVQL_MODE_FINAL && plan->group_mode != EVQL_MODE_PARTIAL) {

@@ -38,7 +38,12 @@ struct AggPlan {
   // count_distinct: index of the (group, value) pair set in EvqlArgs::pairset; the
   // state word counts the pairs this aggregate inserted first
   int distinct_index = -1;
+  // EVQL_FLOAT_SUM_EXACT: the sum is kept as two integer words (high part, low 31
+  // bits) of multiples of a quantum; index into EvqlArgs::fscale / fbound
+  int exact_index = -1;
 };
+
+static const int kMaxExactSums = 4;
 
 static const int kMaxDistinct = 4;
 
@@ -58,6 +63,7 @@ struct KernelPlan {
   bool need_first_row = false;
   bool has_row_filter = false;
   int n_distinct = 0;  // count_distinct aggregates (one HBM pair set each)
+  int n_exact = 0;     // exact float sums
   // slot layout: word 0 identity, [second identity word], [first_row], states.
   // Hashed keys (several keys / strings) are identified by TWO independent
   // 64-bit hashes of the key tuple -- like the reference, which identifies a

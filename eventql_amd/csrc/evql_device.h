@@ -64,7 +64,24 @@ struct EvqlArgs {
   // / flags
   u64* pairset[4];
   u64 pairset_cap[4];
+  // EVQL_FLOAT_SUM_EXACT: per exact sum, 1 / quantum (a power of two) and the bound
+  // of |argument|
+  double fscale[4];
+  double fbound[4];
 };
+
+#define EVQL_ST_SUM_RANGE 32u
+// the multiple of the quantum nearest to x, split into a signed high part and 31 low
+// bits that are added up separately as integers
+__device__ __forceinline__ void evql_fix(const EvqlArgs& A, int k, double x, u64& hi, u64& lo) {
+  if (!(fabs(x) <= A.fbound[k])) {  // also NaN
+    atomicOr(&A.status[0], EVQL_ST_SUM_RANGE);
+    x = 0.0;
+  }
+  const long long q = __double2ll_rn(x * A.fscale[k]);
+  hi = (u64) (q >> 31);
+  lo = (u64) (q & 0x7fffffffll);
+}
 
 // ---------------------------------------------------------------------------
 // hashing: slot placement only (identity is the full 64-bit word)

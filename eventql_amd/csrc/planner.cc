@@ -509,8 +509,16 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
           a.nwords = 1;
           break;
         case EVQL_AGG_SUM_FLOAT64:
-          kp.states.push_back({1});
-          a.nwords = 1;
+          if (plan->float_sum_mode == EVQL_FLOAT_SUM_EXACT) {
+            if (kp.n_exact >= kMaxExactSums) return unsup("too many exact float sums");
+            a.exact_index = kp.n_exact++;
+            kp.states.push_back({0});  // high part (signed, two's complement adds)
+            kp.states.push_back({0});  // low 31 bits
+            a.nwords = 2;
+          } else {
+            kp.states.push_back({1});
+            a.nwords = 1;
+          }
           break;
         case EVQL_AGG_COUNT_DISTINCT_UINT64:
           // aggregate.cc:77-137 (std::set per group): the state word counts the

@@ -3,6 +3,7 @@
 #include "runtime.h"
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1046,6 +1047,140 @@ static uint64_t word_identity(int op) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// EVQL_FLOAT_SUM_EXACT: bound of |argument| and the quantum of every exact sum
+// ---------------------------------------------------------------------------
+// upper bound of |e| given upper bounds of |column i|; +inf = unknown
+static double expr_abs_bound(const ExprPtr& e, const std::vector<double>& colmax) {
+  const double inf = std::numeric_limits<double>::infinity();
+  switch (e->kind) {
+    case Expr::INPUT:
+      return e->input < colmax.size() ? colmax[e->input] : inf;
+    case Expr::LITERAL:
+      switch (e->type) {
+        case EVQL_T_UINT64: case EVQL_T_TIMESTAMP64: return double(e->lit_bits);
+        case EVQL_T_INT64: return std::fabs(double(int64_t(e->lit_bits)));
+        case EVQL_T_FLOAT64: {
+          double d;
+          memcpy(&d, &e->lit_bits, 8);
+          return std::fabs(d);
+        }
+        case EVQL_T_BOOL: return 1.0;
+        default: return inf;
+      }
+    case Expr::IF:
+      return std::max(expr_abs_bound(e->args[1], colmax), expr_abs_bound(e->args[2], colmax));
+    case Expr::CALL: {
+      std::vector<double> b;
+      for (const auto& a : e->args) b.push_back(expr_abs_bound(a, colmax));
+      switch (e->family) {
+        case EVQL_FAM_ADD: case EVQL_FAM_SUB: return b[0] + b[1];
+        case EVQL_FAM_MUL: return b[0] * b[1];
+        case EVQL_FAM_MOD: return b[0];
+        case EVQL_FAM_DIV:
+          if (e->type != EVQL_T_FLOAT64) return b[0];
+          if (e->args[1]->kind == Expr::LITERAL) {
+            double d;
+            memcpy(&d, &e->args[1]->lit_bits, 8);
+            if (d != 0.0) return b[0] / std::fabs(d);
+          }
+          return inf;
+        case EVQL_FAM_TO_INT64: case EVQL_FAM_TO_TIMESTAMP64: return b[0];
+        case EVQL_FAM_CMP: case EVQL_FAM_EQ: case EVQL_FAM_NEQ: case EVQL_FAM_LT:
+        case EVQL_FAM_LTE: case EVQL_FAM_GT: case EVQL_FAM_GTE: case EVQL_FAM_LOGICAL_AND:
+        case EVQL_FAM_LOGICAL_OR: case EVQL_FAM_NEG:
+          return 1.0;
+        default: return inf;
+      }
+    }
+    default:
+      return inf;
+  }
+}
+
+// maximum |value| of scan column i as the kernel sees it (cached per table column)
+static Status column_abs_max(evql_query* q, size_t i, double* out) {
+  evql_table* t = q->table;
+  hipStream_t s = q->ctx->stream;
+  const ColAccess& c = q->kp.cols[i];
+  if (c.string_hash) {
+    *out = std::numeric_limits<double>::infinity();
+    return Status();
+  }
+  const bool is_float = c.stype == EVQL_T_FLOAT64 && !c.from_uint_to_float;
+  const std::string key = c.name + (is_float ? "#f" : "#u");
+  if (!q->nested) {
+    auto hit = t->col_absmax.find(key);
+    if (hit != t->col_absmax.end()) {
+      *out = hit->second;
+      return Status();
+    }
+  }
+  RtColumn rc{};
+  rc.pages = c.layout_index >= 0 ? t->d_pages[c.layout_index][0] : nullptr;
+  rc.mode = c.mode;
+  rc.bits = c.bits;
+  uint64_t n = t->layout.num_rows;
+  if (q->nested) {
+    rc.mode = ColAccess::SOA;
+    rc.soa = q->nested_flat[i];
+    n = q->nested_rows;
+  } else if (c.packed) {
+    const MaterializedColumn& m = t->materialized[c.name];
+    rc.pages = m.d_packed_pages;
+    rc.base = m.d_packed;
+  } else if (c.mode == ColAccess::SOA) {
+    rc.soa = t->materialized[c.name].d_values;
+  }
+  DevBuf<uint64_t> d_max;
+  HIP_TRY(d_max.alloc(8));
+  HIP_TRY(hipMemsetAsync(d_max, 0, 8, s));
+  HIP_TRY(launch_column_abs_max(t->d_image, rc, n, is_float ? 1 : 0, d_max, s));
+  uint64_t bits = 0;
+  HIP_TRY(hipMemcpyAsync(&bits, d_max, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  double m;
+  if (is_float) {
+    memcpy(&m, &bits, 8);  // (NaN / inf order above every finite |x| as integers)
+    if (!(m == m)) m = std::numeric_limits<double>::infinity();
+  } else {
+    m = double(bits);
+  }
+  if (!q->nested) t->col_absmax[key] = m;
+  *out = m;
+  return Status();
+}
+
+static Status choose_exact_sum_scales(evql_query* q) {
+  std::vector<double> colmax(q->kp.cols.size(), std::numeric_limits<double>::infinity());
+  bool have = false;
+  for (const auto& a : q->kp.aggs) {
+    if (a.exact_index < 0) continue;
+    double bound = q->float_sum_bound;
+    if (!(bound > 0)) {
+      if (!have) {
+        for (size_t i = 0; i < colmax.size(); ++i) {
+          Status st = column_abs_max(q, i, &colmax[i]);
+          if (!st.ok()) return st;
+        }
+        have = true;
+      }
+      bound = a.arg ? expr_abs_bound(a.arg, colmax) : 0.0;
+      if (!std::isfinite(bound)) {
+        return Status::error(EVQL_ENOTSUP, "exact float sum: no finite bound of the argument "
+                                           "follows from the table; pass float_sum_bound");
+      }
+    }
+    // quantum 2^e with bound * 2^-e < 2^61: |q| < 2^61, the high parts (|q| >> 31
+    // < 2^30) and the low parts (< 2^31) of up to 2^32 rows add up inside 64 bits
+    int ex = 0;
+    std::frexp(bound > 0 ? bound : 1.0, &ex);  // bound < 2^ex
+    q->fsum_exp[a.exact_index] = ex - 61;
+    q->fsum_bound[a.exact_index] = bound;
+  }
+  return Status();
+}
+
 static Status compile_plan_kernels(evql_query* q);
 
 static Status apply_where_resets(evql_query* q, const evql_table::LeafLevels& leaf);
@@ -1088,6 +1223,10 @@ Status query_prepare(evql_query* q) {
   if (repacked && !q->kp.partitioned) {
     // the access modes changed: block / unroll / LDS table are chosen again
     choose_launch_shape(&q->kp, q->groups_hint);
+  }
+  if (q->kp.n_exact > 0) {
+    Status stb = choose_exact_sum_scales(q);
+    if (!stb.ok()) return stb;
   }
   Status st = compile_plan_kernels(q);
   if (!st.ok()) return st;
@@ -1211,6 +1350,10 @@ static void fill_host_args(evql_query* q, HostArgs* ap) {
   a.gcap = q->gcap;
   a.status = q->d_status;
   a.counters = q->d_counters;
+  for (int k = 0; k < kp.n_exact; ++k) {
+    a.fscale[k] = std::ldexp(1.0, -q->fsum_exp[k]);
+    a.fbound[k] = q->fsum_bound[k];
+  }
   for (size_t i = 0; i < kp.cols.size(); ++i) {
     const ColAccess& c = kp.cols[i];
     a.col[i].base = t->d_image;
@@ -1494,6 +1637,9 @@ Status query_finish(evql_query* q) {
     HIP_TRY(hipMemcpy(status, q->d_status, 16, hipMemcpyDeviceToHost));
     if (status[0] & 1u) return Status::error(EVQL_ERUNTIME, "division by zero");
     if (status[0] & 4u) return Status::error(EVQL_ERUNTIME, "modulo by zero");
+    if (status[0] & 32u) {
+      return Status::error(EVQL_ERUNTIME, "exact float sum: a value is not finite or exceeds the bound");
+    }
     if (status[0] & (2u | 8u | 16u)) {
       // group table / count_distinct pair set / dense record buffer too small: grow
       // and run again
@@ -1878,6 +2024,13 @@ static Status fetch_results(evql_query* q) {
 // ---------------------------------------------------------------------------
 // result emission: GroupByExpression::nextBatch (groupby.cc:187-220)
 // ---------------------------------------------------------------------------
+// EVQL_FLOAT_SUM_EXACT: (sum of high parts) * 2^31 + (sum of low parts) multiples of
+// 2^e, rounded to nearest once
+static double exact_sum_value(uint64_t hi, uint64_t lo, int e) {
+  const __int128 total = (__int128(int64_t(hi)) << 31) + __int128(int64_t(lo));
+  return std::ldexp(double(total), e);  // (int128 -> double rounds to nearest even)
+}
+
 static Value agg_value(const evql_query* q, const AggPlan& a, const uint64_t* st) {
   Value v;
   v.tag = 0;
@@ -1896,6 +2049,10 @@ static Value agg_value(const evql_query* q, const AggPlan& a, const uint64_t* st
     case EVQL_AGG_SUM_FLOAT64:
       v.type = EVQL_T_FLOAT64;
       v.bits = w0;
+      if (a.exact_index >= 0) {
+        const double d = exact_sum_value(w0, st[a.first_word + 1], q->fsum_exp[a.exact_index]);
+        memcpy(&v.bits, &d, 8);
+      }
       break;
     case EVQL_AGG_MIN_UINT64:
     case EVQL_AGG_MAX_UINT64:
@@ -1944,7 +2101,8 @@ static void put_varuint(std::vector<uint8_t>* b, uint64_t v) {
 // instance_savestate of each aggregate: count / sum = LEB128 varuint
 // (aggregate.cc:55-57,171-173,207-209); build-supplied: sum_float64 = 8 raw
 // bytes, min/max/mean = varuint(non-null count) + 8 raw bytes
-static void save_state(const AggPlan& a, const uint64_t* st, std::vector<uint8_t>* out) {
+static void save_state(const evql_query* q, const AggPlan& a, const uint64_t* st,
+                       std::vector<uint8_t>* out) {
   const uint64_t w0 = st[a.first_word];
   const uint8_t* p = reinterpret_cast<const uint8_t*>(&w0);
   switch (a.fn) {
@@ -1954,6 +2112,12 @@ static void save_state(const AggPlan& a, const uint64_t* st, std::vector<uint8_t
       put_varuint(out, w0);
       return;
     case EVQL_AGG_SUM_FLOAT64:
+      if (a.exact_index >= 0) {  // the wire carries the rounded double
+        const double d = exact_sum_value(w0, st[a.first_word + 1], q->fsum_exp[a.exact_index]);
+        const uint8_t* pd = reinterpret_cast<const uint8_t*>(&d);
+        out->insert(out->end(), pd, pd + 8);
+        return;
+      }
       out->insert(out->end(), p, p + 8);
       return;
     default:
@@ -2017,7 +2181,12 @@ Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n,
         case EVQL_AGG_COUNT:
         case EVQL_AGG_SUM_UINT64: ok.type = 0; break;
         case EVQL_AGG_SUM_INT64: ok.type = 1; break;
-        case EVQL_AGG_SUM_FLOAT64: ok.type = 2; break;
+        case EVQL_AGG_SUM_FLOAT64:
+          if (a.exact_index >= 0) {
+            return Status::error(EVQL_ENOTSUP, "ORDER BY an exact float sum is not fused");
+          }
+          ok.type = 2;
+          break;
         case EVQL_AGG_MEAN_UINT64:
         case EVQL_AGG_MEAN_INT64:
         case EVQL_AGG_MEAN_FLOAT64:
@@ -2163,7 +2332,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
       const LoweredProgram& lp = q->select[i];
       Value out;
       if (partial && lp.is_aggregate) {
-        save_state(kp.aggs[q->select_agg_index[i]], st, &pdata);
+        save_state(q, kp.aggs[q->select_agg_index[i]], st, &pdata);
         continue;
       }
       if (lp.is_aggregate) {

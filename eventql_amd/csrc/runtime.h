@@ -36,6 +36,8 @@ struct HostArgs {
   HostColArg col[16];
   uint64_t* pairset[4];
   uint64_t pairset_cap[4];
+  double fscale[4];
+  double fbound[4];
 };
 
 struct Status {
@@ -161,6 +163,9 @@ struct evql_table {
   std::vector<std::vector<uint64_t*>> d_pages;
   std::vector<uint64_t> payload_bytes;
   std::map<std::string, MaterializedColumn> materialized;
+  // maximum |value| per column ("name#f" float view, "name#u" integer view): bounds of
+  // exact float sums (EVQL_FLOAT_SUM_EXACT)
+  std::map<std::string, double> col_absmax;
   // nested scans: column flattened to one value per output row of the scans whose
   // deepest repeated column is `leaf` -- key (column, leaf) layout indices.  Like
   // `materialized`, decoded once per table and shared by every operator.
@@ -193,6 +198,11 @@ struct evql_query {
   std::vector<bool> select_passthrough;
   uint32_t group_mode = EVQL_MODE_FINAL;
   uint64_t groups_hint = 0;
+  // EVQL_FLOAT_SUM_EXACT: quantum exponent / bound per exact sum (index AggPlan::exact_index)
+  uint32_t float_sum_mode = 0;
+  double float_sum_bound = 0;
+  int fsum_exp[4] = {0, 0, 0, 0};   // quantum = 2^fsum_exp
+  double fsum_bound[4] = {0, 0, 0, 0};
   uint64_t row_begin = 0, row_end = 0;
   std::vector<uint8_t> row_filter_host;
   uint64_t row_filter_len = 0;

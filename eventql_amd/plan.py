@@ -357,7 +357,8 @@ class Plan:
 
     def __init__(self, schema, select=(), group_by=(), where=None,
                  scan_select=None, mode=K.MODE_FINAL, scan_mode=K.SCAN_FLAT,
-                 groups_hint=0, row_filter=None, row_end=0, row_begin=0):
+                 groups_hint=0, row_filter=None, row_end=0, row_begin=0,
+                 float_sum_mode=0, float_sum_bound=0.0):
         self.schema = dict(schema)
         # scan columns: WHERE first, then group exprs, then select exprs -- the
         # order in which QueryPlanBuilder resolves references
@@ -429,6 +430,8 @@ class Plan:
         d.groups_hint = groups_hint
         d.row_begin = row_begin
         d.row_end = row_end
+        d.float_sum_mode = float_sum_mode
+        d.float_sum_bound = float_sum_bound
         self.desc = d
 
     @property

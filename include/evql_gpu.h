@@ -406,7 +406,27 @@ typedef struct {
   /* row range (partition slice) [row_begin, row_end); row_end == 0 => all */
   uint64_t row_begin;
   uint64_t row_end;
+
+  /* sum#float64 (build-supplied): how the doubles are added up.
+   *   EVQL_FLOAT_SUM_FAST  atomic double adds in whatever order the rows arrive:
+   *                        within 1e-6 of the reference's row-order sum, not
+   *                        bit-stable from run to run
+   *   EVQL_FLOAT_SUM_EXACT every value is rounded once to a multiple of a fixed power
+   *                        of two q (chosen so that 2^61 q covers float_sum_bound) and
+   *                        the multiples are added as integers: the result does not
+   *                        depend on the order of the rows, the run, the number of
+   *                        workgroups or -- with the same bound on every partition --
+   *                        on how the table is split over GPUs.  Error <= rows * q / 2.
+   * float_sum_bound: an upper bound of |argument| over all rows; 0 = derived from the
+   * table (maximum |value| of the columns the argument reads, through the
+   * expression); EVQL_ENOTSUP when no finite bound can be derived.  A row beyond the
+   * bound (or NaN / infinity) fails the query with EVQL_ERUNTIME. */
+  uint32_t float_sum_mode;
+  double float_sum_bound;
 } evql_plan_desc_t;
+
+#define EVQL_FLOAT_SUM_FAST 0
+#define EVQL_FLOAT_SUM_EXACT 1
 
 /* Lowers the plan to a fused kernel and compiles it (cached by fingerprint).
  * Replaces DefaultScheduler::buildGroupByExpression + buildSequentialScan

@@ -1040,3 +1040,78 @@ def test_plan_without_a_hint_finds_the_partitioned_path_by_itself(ctx):
         q.close()
     finally:
         t.close()
+
+
+def test_exact_float_sums(ctx, mixed):
+    """EVQL_FLOAT_SUM_EXACT: every value is rounded once to a multiple of a power of two
+    and the multiples are added as integers -- bit-stable from run to run and for any
+    split of the rows; on this table (v = integer / 1024) even the exactly rounded sum"""
+    import math
+    import threading
+    t, img, c = mixed
+    k, v, nv, a = col("k"), col("v"), col("nv"), col("a")
+    kw = dict(select=[k, sum_(v), sum_(v * 1.5 - 2.0), sum_(If(a > 30000, nv, 0.0)), count(1)],
+              group_by=[k], where=W)
+    plan = Plan(T.MIXED_SCHEMA, float_sum_mode=K.FLOAT_SUM_EXACT, **kw)
+    exp = O.oracle_run(img, Plan(T.MIXED_SCHEMA, **kw))
+    q = t.query(plan)
+    r1 = q.run().rows()
+    r2 = q.run().rows()
+    q.close()
+    assert sorted(map(repr, r1)) == sorted(map(repr, r2))          # run to run
+    T.compare_results(r1, exp.rows(), exp.types, rel=1e-12)
+    # the exactly rounded sum of the passing rows of every group
+    passing = (c["a"] > 30000) & (c["b"] < 30000)
+    want = {}
+    for kk in np.unique(c["k"][passing]):
+        want[int(kk)] = math.fsum(c["v"][passing & (c["k"] == kk)].tolist())
+    got = {r[0]: r[1] for r in r1}
+    assert got == want
+    # any split of the rows over partitions, same bound everywhere: the same bits
+    bound = 1e6
+    single = t.query(Plan(T.MIXED_SCHEMA, float_sum_mode=K.FLOAT_SUM_EXACT, float_sum_bound=bound, **kw))
+    base = sorted(map(repr, single.run().rows()))
+    single.close()
+    for cuts in ([0, 100_000, 300_000], [0, 1, 299_999, 300_000], [0, 77_777, 155_555, 300_000]):
+        nr = len(cuts) - 1
+        hub = E.Hub(nr)
+        out = [None] * nr
+
+        def work(r):
+            cx = E.Context(0)
+            tt = cx.open_image(img)
+            qq = tt.query(Plan(T.MIXED_SCHEMA, float_sum_mode=K.FLOAT_SUM_EXACT,
+                               float_sum_bound=bound, row_begin=cuts[r], row_end=cuts[r + 1], **kw))
+            x = E.Exchange.hub(cx, hub, r)
+            qq.execute()
+            qq.exchange(x, K.EXCHANGE_GATHER_ALL)
+            out[r] = sorted(map(repr, qq.fetch_all().rows()))
+            qq.close(); x.close(); tt.close(); cx.close()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(nr)]
+        [x.start() for x in th]
+        [x.join(timeout=300) for x in th]
+        hub.close()
+        assert all(o == base for o in out), cuts
+    # a bound the data exceeds, and an argument without a derivable bound
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[sum_(v)], float_sum_mode=K.FLOAT_SUM_EXACT,
+                     float_sum_bound=10.0))
+    with pytest.raises(E.EvqlError) as ei:
+        q.run()
+    assert ei.value.code == K.EVQL_ERUNTIME and "bound" in ei.value.msg
+    q.close()
+    with pytest.raises(E.EvqlError) as ei:
+        t.query(Plan(T.MIXED_SCHEMA, select=[sum_(v / (nv + 1.0))], float_sum_mode=K.FLOAT_SUM_EXACT))
+    assert ei.value.code == K.EVQL_ENOTSUP
+    # partial-aggregate rows carry the rounded double (the reference's wire format)
+    q = t.query(Plan(T.MIXED_SCHEMA, select=[k, sum_(v)], group_by=[k], mode=K.MODE_PARTIAL,
+                     float_sum_mode=K.FLOAT_SUM_EXACT))
+    rows = dict(q.run().rows())
+    q.close()
+    full = {int(kk): math.fsum(c["v"][c["k"] == kk].tolist()) for kk in np.unique(c["k"])}
+    import struct
+    assert len(rows) == len(full)
+    for key, data in list(rows.items())[:50]:
+        # data = SValue::encode(k) (1 + 1 + 9 bytes) then the 8 raw bytes of the double
+        kk = struct.unpack_from("<Q", data, 2)[0]
+        assert struct.unpack_from("<d", data, 11)[0] == full[kk]
