@@ -523,10 +523,8 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
         case EVQL_AGG_COUNT_DISTINCT_UINT64:
           // aggregate.cc:77-137 (std::set per group): the state word counts the
           // (group, value) pairs first inserted into the aggregate's HBM pair set.
-          // The sets themselves do not travel: no partial / merged execution.
-          if (plan->group_mode == EVQL_MODE_PARTIAL) {
-            return unsup("count_distinct in a partial aggregate is not lowered");
-          }
+          // PartialGroupBy rows carry the set itself (sorted values, aggregate.cc:111-117):
+          // read back from the pair set at emission.  Between GPUs the sets do not travel.
           if (kp.n_distinct >= kMaxDistinct) return unsup("too many count_distinct aggregates");
           a.distinct_index = kp.n_distinct++;
           kp.states.push_back({0});

@@ -2014,6 +2014,47 @@ static Status fetch_results(evql_query* q) {
       HIP_TRY(hipStreamSynchronize(s));
     }
   }
+  q->distinct_values.clear();
+  if (q->group_mode == EVQL_MODE_PARTIAL && kp.n_distinct > 0) {
+    // count_distinct's saved state is the set itself (aggregate.cc:111-117): the
+    // (group, value, flags) triples of the aggregate's pair set, grouped on the host
+    const uint64_t cap = q->pairset_cap;
+    const bool hashed = kp.key_mode == KEY_HASHED;
+    q->distinct_values.resize(kp.n_distinct);
+    std::vector<uint64_t> host(cap * 3);
+    for (int d = 0; d < kp.n_distinct; ++d) {
+      HIP_TRY(hipMemcpy(host.data(), q->d_pairset[d], cap * 3 * 8, hipMemcpyDeviceToHost));
+      auto& sets = q->distinct_values[d];
+      for (uint64_t sl = 0; sl < cap; ++sl) {
+        uint64_t ident = host[sl], value = host[cap + sl], flags = host[2 * cap + sl];
+        if (ident == ~0ull || value == ~0ull || flags == ~0ull) continue;
+        uint64_t second;
+        if (hashed) {
+          // (a value of 2^64-1 is stored as 2^64-2 with the flags word scrambled: such
+          // a group is found under the unscrambled second identity word)
+          second = flags;
+          if (value == ~0ull - 1 && !sets.count({ident, second})) {
+            const uint64_t alt = flags ^ 0xc2b2ae3d27d4eb4full;
+            bool known = false;
+            for (uint64_t g = 0; g < n && !known; ++g) {
+              const uint64_t* rec = &q->records[g * (nwords + 1)];
+              known = rec[1] == ident && rec[2] == alt;
+            }
+            if (known) {
+              second = alt;
+              value = ~0ull;
+            }
+          }
+        } else {
+          if (flags & 2u) ident = ~0ull;
+          if (flags & 4u) value = ~0ull;
+          second = flags & 1u;  // NULL key
+        }
+        sets[{ident, second}].push_back(value);
+      }
+      for (auto& kv : sets) std::sort(kv.second.begin(), kv.second.end());
+    }
+  }
   q->stats.num_groups = total_groups;
   q->emit_pos = 0;
   q->executed = true;
@@ -2102,8 +2143,24 @@ static void put_varuint(std::vector<uint8_t>* b, uint64_t v) {
 // (aggregate.cc:55-57,171-173,207-209); build-supplied: sum_float64 = 8 raw
 // bytes, min/max/mean = varuint(non-null count) + 8 raw bytes
 static void save_state(const evql_query* q, const AggPlan& a, const uint64_t* st,
-                       std::vector<uint8_t>* out) {
+                       std::vector<uint8_t>* out, const uint64_t* rec = nullptr) {
   const uint64_t w0 = st[a.first_word];
+  if (a.fn == EVQL_AGG_COUNT_DISTINCT_UINT64) {
+    // varuint size, then the values ascending (std::set order, aggregate.cc:111-117)
+    static const std::vector<uint64_t> none;
+    const std::vector<uint64_t>* vals = &none;
+    if (rec && a.distinct_index >= 0 && size_t(a.distinct_index) < q->distinct_values.size()) {
+      const uint64_t kind = rec[0];
+      const uint64_t ident = kind == 1 ? ~0ull : (kind == 2 ? 0 : rec[1]);
+      const uint64_t second = q->kp.key_mode == KEY_HASHED ? rec[2] : (kind == 2 ? 1 : 0);
+      const auto& sets = q->distinct_values[a.distinct_index];
+      auto hit = sets.find({q->kp.key_mode == KEY_NONE ? 0 : ident, second});
+      if (hit != sets.end()) vals = &hit->second;
+    }
+    put_varuint(out, vals->size());
+    for (uint64_t v : *vals) put_varuint(out, v);
+    return;
+  }
   const uint8_t* p = reinterpret_cast<const uint8_t*>(&w0);
   switch (a.fn) {
     case EVQL_AGG_COUNT:
@@ -2332,7 +2389,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
       const LoweredProgram& lp = q->select[i];
       Value out;
       if (partial && lp.is_aggregate) {
-        save_state(q, kp.aggs[q->select_agg_index[i]], st, &pdata);
+        save_state(q, kp.aggs[q->select_agg_index[i]], st, &pdata, rec);
         continue;
       }
       if (lp.is_aggregate) {

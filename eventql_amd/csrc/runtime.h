@@ -276,6 +276,9 @@ struct evql_query {
   std::vector<uint64_t> first_str_off;  // [col][group] offset into the heap
   uint64_t emit_pos = 0;
   std::vector<std::vector<uint8_t>> out_cols;
+  // EVQL_MODE_PARTIAL with count_distinct: the distinct values of every group, per
+  // aggregate, read back from the HBM pair set; key = (identity, identity 2 | NULL flag)
+  std::vector<std::map<std::pair<uint64_t, uint64_t>, std::vector<uint64_t>>> distinct_values;
   // ORDER BY .. LIMIT fused above the GROUP BY (evql_query_set_order)
   std::vector<evql::LoweredProgram> order;  // over the select list
   std::vector<bool> order_desc;

@@ -430,7 +430,7 @@ def test_operators_release_their_device_memory(ctx):
     t.close()
 
 
-def test_count_distinct(mixed, monkeypatch):
+def test_count_distinct(mixed):
     """count_distinct#uint64/uint64; (aggregate.cc:77-137): exact, through the HBM
     pair set, under every key mode, next to other aggregates"""
     from eventql_amd.plan import count_distinct as cd
@@ -454,9 +454,21 @@ def test_count_distinct(mixed, monkeypatch):
         q.export_groups(buf.data_ptr(), 4096)
     assert ei.value.code == K.EVQL_ENOTSUP
     q.close()
-    with pytest.raises(E.EvqlError) as ei:
-        t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(a)], group_by=[k], mode=K.MODE_PARTIAL))
-    assert ei.value.code == K.EVQL_ENOTSUP
+    # PartialGroupBy rows carry the set itself: varuint size, values ascending
+    # (aggregate.cc:111-117) -- byte for byte the oracle's (pinned on the reference's
+    # bytes in test_gpu_ref_csql.py)
+    for kw in (dict(select=[k, cd(a), count(1)], group_by=[k]),
+               dict(select=[cd(b % 97), cd(k)], group_by=[]),
+               dict(select=[nb, cd(a)], group_by=[nb]),
+               dict(select=[k, col("f"), cd(b)], group_by=[k, col("f")]),
+               dict(select=[col("s"), cd(a % 100)], group_by=[col("s")])):
+        plan = Plan(T.MIXED_SCHEMA, mode=K.MODE_PARTIAL, **kw)
+        exp = O.oracle_run(img, plan)
+        e = {exp.keys[20 * i:20 * i + 20]: exp.columns[0][i] for i in range(exp.nrows)}
+        q = t.query(plan)
+        g = dict(q.run().rows())
+        q.close()
+        assert g == e
 
 
 def test_count_distinct_pair_set_regrows(ctx):
