@@ -277,12 +277,15 @@ class Context:
         _check(lib().evql_table_generate(self.h, C.byref(spec), C.byref(t)))
         return Table(self, t)
 
-    def table_from_device_columns(self, columns, values, nulls, num_rows, heaps=None):
+    def table_from_device_columns(self, columns, values, nulls, num_rows, heaps=None,
+                                  levels=None):
         """evql_table_from_device_columns: `columns` as for Writer; values[name] /
         nulls[name] are DEVICE addresses (e.g. torch tensor .data_ptr()) of num_rows
         u64 value words / NULL-flag bytes (nulls only for optional columns);
         heaps[name]: byte heap of a STRING_PLAIN column, whose value words are
-        (length << 40) | offset into it"""
+        (length << 40) | offset into it; levels[name] = (rlevels address | None,
+        dlevels address, num_slots) for a repeated / nested column, whose values are
+        given per slot"""
         names = [c["name"].encode() for c in columns]
         specs = (K.ColumnSpec * len(columns))()
         data = (K.DeviceColumn * len(columns))()
@@ -290,8 +293,9 @@ class Context:
             specs[i] = K.ColumnSpec(names[i], c["logical_type"], c["storage_type"],
                                     c.get("column_id", i + 1), c.get("rlevel_max", 0),
                                     c.get("dlevel_max", 0), c.get("bitpack_max_value", 0))
+            rl, dl, ns = (levels or {}).get(c["name"], (None, None, 0))
             data[i] = K.DeviceColumn(values[c["name"]], (nulls or {}).get(c["name"]),
-                                     (heaps or {}).get(c["name"]))
+                                     (heaps or {}).get(c["name"]), rl, dl, ns)
         t = C.c_void_p()
         _check(lib().evql_table_from_device_columns(self.h, specs, len(columns), data, num_rows,
                                                     C.byref(t)))

@@ -213,7 +213,10 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
     return nullptr;
   }
   PlanBuffers pb;
-  if (!buildPlanDesc(txn, group, seqscan, kind, opts_.partial && group != nullptr, &pb, why)) {
+  // a data node serving EVQL_OP_QUERY_PARTIALAGGR gets a GroupByNode marked partial
+  // (server/sql/scheduler.cc:59-64): the operator then emits PartialGroupBy rows
+  const bool partial = group != nullptr && (opts_.partial || group->isPartialAggregation());
+  if (!buildPlanDesc(txn, group, seqscan, kind, partial, &pb, why)) {
     return nullptr;
   }
   evql_query_t* q = nullptr;

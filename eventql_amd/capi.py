@@ -137,7 +137,8 @@ class ColumnSpec(C.Structure):
 
 
 class DeviceColumn(C.Structure):
-    _fields_ = [("values", C.c_void_p), ("nulls", C.c_void_p), ("bytes", C.c_void_p)]
+    _fields_ = [("values", C.c_void_p), ("nulls", C.c_void_p), ("bytes", C.c_void_p),
+                ("rlevels", C.c_void_p), ("dlevels", C.c_void_p), ("num_slots", C.c_uint64)]
 
 
 class ColumnBuf(C.Structure):

@@ -1824,6 +1824,19 @@ __global__ void __launch_bounds__(kBlock) k_wr_leb_emit(u8* image, const u64* pa
   }
 }
 
+// repeated / nested columns arrive as one (r, d, value) triple per slot: the NULL flags
+// the compaction reads (d != dlevel_max) and the level streams as words for the
+// bit-packer
+__global__ void __launch_bounds__(kBlock) k_wr_levels(const u8* levels, u64 n, u32 dmax,
+                                                      u8* nulls, u64* words) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u8 l = levels[i];
+    if (nulls) nulls[i] = l != dmax ? 1 : 0;
+    if (words) words[i] = l;
+  }
+}
+
 // STRING_PLAIN streams (LenencStringPageWriter, page_writer_lenencstring.cc:37-69):
 // `varuint length, bytes` per value.  A value is (len << 40 | offset into `heap`).
 __device__ __forceinline__ u32 wr_str_size(u64 sp) {
@@ -1929,6 +1942,14 @@ hipError_t launch_synth(const SynthArgs* d_args, uint64_t num_rows, hipStream_t 
   if (nchunks == 0) return hipSuccess;
   hipLaunchKernelGGL(k_synth, dim3((unsigned) ((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      s, d_args, (u64) nchunks);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_levels(const uint8_t* levels, uint64_t n, uint32_t dmax, uint8_t* nulls,
+                            uint64_t* words, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_levels, dim3(grid_for(n)), dim3(kBlock), 0, s, levels, (u64) n, dmax,
+                     nulls, (u64*) words);
   return hipGetLastError();
 }
 

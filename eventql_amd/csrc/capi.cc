@@ -390,7 +390,8 @@ int evql_table_from_device_columns(evql_ctx_t* ctx, const evql_column_spec_t* co
           cs.storage_type == ColumnEncoding::BOOLEAN_BITPACKED ? 1u : 0xffffffffu;
     }
     specs.push_back(cs);
-    in.push_back({data[i].values, data[i].nulls, data[i].bytes});
+    in.push_back({data[i].values, data[i].nulls, data[i].bytes, data[i].rlevels, data[i].dlevels,
+                  data[i].num_slots});
   }
   evql_table* t = nullptr;
   Status st = table_from_device_columns(ctx, specs, in, num_rows, &t);

@@ -17,6 +17,10 @@
 // each stream of an optional column fits one page, and exactly for required
 // columns of any size.  Readers follow the page index, so every order is valid.
 //
+// Repeated / nested columns arrive shredded, one (r, d, value) triple per slot: their
+// level streams are bit-packed from the level arrays and the values of the slots with
+// d == dlevel_max compacted like an optional column's.
+//
 // String columns (LenencStringPageWriter, page_writer_lenencstring.cc:37-69) arrive
 // as one word per row, (length << 40) | offset into a byte heap in HBM -- the form in
 // which the scan side names a string of a resident table (MaterializedColumn::d_strpos)
@@ -39,6 +43,10 @@ namespace evql {
 
 namespace {
 struct ColumnWork {
+  uint64_t nslots = 0;              // level-stream length (= rows for flat columns)
+  DevBuf<uint8_t> nulls_owned;      // nested: d != dlevel_max per slot
+  const uint8_t* nulls = nullptr;
+  DevBuf<uint64_t> rwords, dwords;  // nested: the level streams as words
   DevBuf<uint64_t> dense_owned;
   const uint64_t* dense = nullptr;  // defined values in row order
   uint64_t ndef = 0;
@@ -61,15 +69,20 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
                                  const std::vector<DeviceColumnIn>& in, uint64_t n,
                                  evql_table** out) {
   hipStream_t s = ctx->stream;
-  const uint64_t ntiles = (n + kDecodeTile - 1) / kDecodeTile;
   std::vector<ColumnWork> work(specs.size());
 
   // ---- pass 1: value counts and encoded sizes ------------------------------------------
   for (size_t i = 0; i < specs.size(); ++i) {
     const ColumnSpec& c = specs[i];
     ColumnWork& w = work[i];
-    if (c.rlevel_max > 0 || c.dlevel_max > 1) {
-      return Status::error(EVQL_ENOTSUP, "device writer: repeated / nested column " + c.name);
+    const bool nested = c.rlevel_max > 0 || c.dlevel_max > 1;
+    w.nslots = nested ? in[i].num_slots : n;
+    if (nested) {
+      if (in[i].nulls || (w.nslots && (!in[i].dlevels || (c.rlevel_max > 0 && !in[i].rlevels)))) {
+        return Status::error(EVQL_EARG, "device writer: a repeated / nested column takes level "
+                                        "arrays per slot: " + c.name);
+      }
+      if (w.nslots < n) return Status::error(EVQL_EARG, "device writer: fewer slots than rows: " + c.name);
     }
     const bool is_string = c.storage_type == ColumnEncoding::STRING_PLAIN;
     if (is_string != (c.logical_type == ColumnType::STRING)) {
@@ -78,22 +91,35 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
     if (is_string && !in[i].bytes && n) {
       return Status::error(EVQL_EARG, "device writer: string column without a byte heap: " + c.name);
     }
-    if ((c.dlevel_max > 0) != (in[i].nulls != nullptr)) {
+    if (!nested && (c.dlevel_max > 0) != (in[i].nulls != nullptr)) {
       return Status::error(EVQL_EARG, "device writer: NULL flags are given exactly for optional "
                                       "columns (dlevel_max 1): " + c.name);
     }
-    if (!in[i].values && n) return Status::error(EVQL_EARG, "device writer: no values: " + c.name);
+    if (!in[i].values && w.nslots) return Status::error(EVQL_EARG, "device writer: no values: " + c.name);
     w.dense = in[i].values;
-    w.ndef = n;
-    if (c.dlevel_max > 0 && n) {
+    w.ndef = w.nslots;
+    w.nulls = in[i].nulls;
+    if (nested && w.nslots) {
+      // slots without a value (d != dlevel_max) as NULL flags; level streams as words
+      HIP_TRY(w.nulls_owned.alloc(w.nslots));
+      HIP_TRY(w.dwords.alloc(w.nslots * 8));
+      HIP_TRY(launch_wr_levels(in[i].dlevels, w.nslots, c.dlevel_max, w.nulls_owned, w.dwords, s));
+      if (c.rlevel_max > 0) {
+        HIP_TRY(w.rwords.alloc(w.nslots * 8));
+        HIP_TRY(launch_wr_levels(in[i].rlevels, w.nslots, 0, nullptr, w.rwords, s));
+      }
+      w.nulls = w.nulls_owned;
+    }
+    if (c.dlevel_max > 0 && w.nslots) {
+      const uint64_t nt = (w.nslots + kDecodeTile - 1) / kDecodeTile;
       DevBuf<uint64_t> d_tiles;
-      HIP_TRY(d_tiles.alloc((ntiles + 2) * 8));
-      HIP_TRY(launch_wr_count_defined(in[i].nulls, n, d_tiles, s));
-      HIP_TRY(launch_exclusive_scan(d_tiles, ntiles, d_tiles.p + ntiles, s));
-      HIP_TRY(hipMemcpyAsync(&w.ndef, d_tiles.p + ntiles, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(d_tiles.alloc((nt + 2) * 8));
+      HIP_TRY(launch_wr_count_defined(w.nulls, w.nslots, d_tiles, s));
+      HIP_TRY(launch_exclusive_scan(d_tiles, nt, d_tiles.p + nt, s));
+      HIP_TRY(hipMemcpyAsync(&w.ndef, d_tiles.p + nt, 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       HIP_TRY(w.dense_owned.alloc(w.ndef * 8));
-      HIP_TRY(launch_wr_compact(in[i].values, in[i].nulls, d_tiles, n, w.dense_owned, s));
+      HIP_TRY(launch_wr_compact(in[i].values, w.nulls, d_tiles, w.nslots, w.dense_owned, s));
       HIP_TRY(hipStreamSynchronize(s));
       w.dense = w.dense_owned;
     }
@@ -170,10 +196,17 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
     cl.rlevel_max = c.rlevel_max;
     cl.dlevel_max = c.dlevel_max;
     uint64_t payload = 0;
+    // (ColumnWriter::write* appends the repetition level, then the definition level,
+    // then the value: ColumnWriter.cc:59-89)
+    if (c.rlevel_max > 0) {
+      const uint32_t rbits = bitpack_width(c.rlevel_max);
+      bitpacked_pages(PageKind::RLEVEL, c.column_id, w.nslots, rbits, &cl.rlevel_pages);
+      if (w.nslots) payload += 4 + 16ull * rbits * ((w.nslots + 127) / 128);
+    }
     if (c.dlevel_max > 0) {
       const uint32_t dbits = bitpack_width(c.dlevel_max);
-      bitpacked_pages(PageKind::DLEVEL, c.column_id, n, dbits, &cl.dlevel_pages);
-      if (n) payload += 4 + 16ull * dbits * ((n + 127) / 128);
+      bitpacked_pages(PageKind::DLEVEL, c.column_id, w.nslots, dbits, &cl.dlevel_pages);
+      if (w.nslots) payload += 4 + 16ull * dbits * ((w.nslots + 127) / 128);
     }
     switch (c.storage_type) {
       case ColumnEncoding::UINT64_PLAIN:
@@ -235,7 +268,7 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
   // zero only the last pages (PageManager pages start zero-filled), the index
   // and the slack
   for (const auto& cl : t->layout.columns) {
-    for (const std::vector<PageRef>* list : {&cl.dlevel_pages, &cl.data_pages}) {
+    for (const std::vector<PageRef>* list : {&cl.rlevel_pages, &cl.dlevel_pages, &cl.data_pages}) {
       if (list->empty()) continue;
       HIP_TRY(hipMemsetAsync(t->d_image + list->back().offset, 0, list->back().size, s));
     }
@@ -251,11 +284,18 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
     const ColumnSpec& c = specs[i];
     const ColumnWork& w = work[i];
     const ColumnLayout& cl = t->layout.columns[i];
+    if (!cl.rlevel_pages.empty()) {
+      const uint32_t maxv = c.rlevel_max;
+      HIP_TRY(hipMemcpy(t->d_image + cl.rlevel_pages[0].offset, &maxv, 4, hipMemcpyHostToDevice));
+      HIP_TRY(launch_wr_bitpack(t->d_image, t->d_pages[i][1], w.rwords, nullptr, w.nslots,
+                                bitpack_width(c.rlevel_max), s));
+    }
     if (!cl.dlevel_pages.empty()) {
       const uint32_t maxv = c.dlevel_max;
       HIP_TRY(hipMemcpy(t->d_image + cl.dlevel_pages[0].offset, &maxv, 4, hipMemcpyHostToDevice));
-      HIP_TRY(launch_wr_bitpack(t->d_image, t->d_pages[i][2], nullptr, in[i].nulls, n,
-                                bitpack_width(c.dlevel_max), s));
+      // flat optional columns: the levels are 1 - NULL flag; nested ones: given
+      HIP_TRY(launch_wr_bitpack(t->d_image, t->d_pages[i][2], w.dwords.p, w.dwords.p ? nullptr : w.nulls,
+                                w.nslots, bitpack_width(c.dlevel_max), s));
     }
     if (cl.data_pages.empty()) continue;
     switch (c.storage_type) {

@@ -313,6 +313,10 @@ struct DeviceColumnIn {
   const uint64_t* values;  // device, num_rows value words
   const uint8_t* nulls;    // device, num_rows bytes (1 = NULL) or nullptr
   const uint8_t* bytes;    // device, string columns: the heap `values` point into
+  // repeated / nested columns: one (r, d, value) triple per SLOT
+  const uint8_t* rlevels;  // device, num_slots bytes (rlevel_max > 0)
+  const uint8_t* dlevels;  // device, num_slots bytes (instead of `nulls`)
+  uint64_t num_slots;      // 0 = one slot per row
 };
 Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& specs,
                                  const std::vector<DeviceColumnIn>& in, uint64_t num_rows,

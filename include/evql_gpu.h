@@ -330,15 +330,23 @@ typedef struct {
   const uint8_t* bytes;   /* DEVICE pointer, STRING_PLAIN columns only: the byte heap;
                            * values[i] = (length << 40) | offset of string i in it
                            * (length < 2^24, offset < 2^40).  NULL otherwise */
+  /* repeated / nested columns (rlevel_max > 0 or dlevel_max > 1), shredded as
+   * RecordShredder does (io/cstable/RecordShredder.cc:113-176): one (r, d, value)
+   * triple per SLOT, values[] / the level arrays num_slots long; a slot with
+   * d != dlevel_max carries no value.  `nulls` stays NULL for such columns. */
+  const uint8_t* rlevels; /* DEVICE pointer: num_slots bytes, or NULL when rlevel_max == 0 */
+  const uint8_t* dlevels; /* DEVICE pointer: num_slots bytes */
+  uint64_t num_slots;     /* 0 => one slot per row (flat columns) */
 } evql_device_column_t;
 /*
  * Encodes `ncols` SoA columns that sit in HBM into a cstable v0.2.0 image, in
  * HBM, and returns it as a table (evql_table_download_image / _write_file give
- * the file).  Flat schemas: required or optional (dlevel_max 1) columns in
+ * the file).  Required or optional (dlevel_max 1) columns in
  * UINT64_PLAIN, FLOAT_IEEE754, UINT32_PLAIN, UINT32_BITPACKED,
  * BOOLEAN_BITPACKED, UINT64_LEB128 or STRING_PLAIN (LenencStringPageWriter,
- * io/cstable/columns/page_writer_lenencstring.cc:37-69); repeated / nested columns
- * answer EVQL_ENOTSUP (evql_writer_* covers them on the host).  Pages are placed
+ * io/cstable/columns/page_writer_lenencstring.cc:37-69).  Repeated / nested columns
+ * are given as level arrays + values per slot (ColumnWriter::write*(r, d, v),
+ * io/cstable/ColumnWriter.cc:59-89).  Pages are placed
  * column after column (an optional column's definition levels before its data);
  * for required columns the file is byte-identical to the one evql_writer_*
  * produces from the same values.
