@@ -41,6 +41,9 @@ struct AggPlan {
   // EVQL_FLOAT_SUM_EXACT: the sum is kept as two integer words (high part, low 31
   // bits) of multiples of a quantum; index into EvqlArgs::fscale / fbound
   int exact_index = -1;
+  // partitioned path: the argument is an unsigned value known to stay below 2^32 - 1
+  // (column statistics, runtime.cc choose_tuple_widths); it travels as 32 bits
+  bool narrow_arg = false;
 };
 
 static const int kMaxExactSums = 4;
@@ -80,6 +83,10 @@ struct KernelPlan {
   // of tuples, then aggregate each bucket in LDS (codegen_kernels.inc)
   bool partitioned = false;
   int part_bits = 12;
+  // partition tuples are arrays of 32-bit words: the identity of a single unsigned key
+  // and the first-row index travel as 32 bits where the table's statistics bound them
+  bool narrow_ident = false;
+  bool narrow_first_row = false;
   // nested scans whose WHERE reads columns of different repetition depth: an extra
   // kernel (evql_where_rows) writes the predicate of every row, from which the runtime
   // reproduces the reference's reset of parent values behind a rejected row
@@ -94,6 +101,8 @@ bool partitioned_path_possible(const KernelPlan& kp);
 
 // the generated translation unit (device library excluded)
 std::string generate_kernel_source(const KernelPlan& kp);
+// 32-bit words of one partition tuple (identity, [identity 2], [row], update words)
+int partition_tuple_u32_words(const KernelPlan& kp);
 
 // the embedded text of evql_device.h
 const char* device_library_source();

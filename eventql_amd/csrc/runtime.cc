@@ -1181,6 +1181,61 @@ static Status choose_exact_sum_scales(evql_query* q) {
   return Status();
 }
 
+// ---------------------------------------------------------------------------
+// partitioned path: which tuple members fit 32 bits
+// ---------------------------------------------------------------------------
+// upper bound of the unsigned value of e given upper bounds of the columns; +inf where
+// the value may wrap or is not an unsigned integer
+static double expr_unsigned_bound(const ExprPtr& e, const std::vector<double>& colmax) {
+  const double inf = std::numeric_limits<double>::infinity();
+  const bool uns = e->type == EVQL_T_UINT64 || e->type == EVQL_T_TIMESTAMP64 || e->type == EVQL_T_BOOL;
+  if (!uns) return inf;
+  switch (e->kind) {
+    case Expr::INPUT:
+      return e->input < colmax.size() ? colmax[e->input] : inf;
+    case Expr::LITERAL:
+      return e->type == EVQL_T_BOOL ? 1.0 : double(e->lit_bits);
+    case Expr::IF:
+      return std::max(expr_unsigned_bound(e->args[1], colmax), expr_unsigned_bound(e->args[2], colmax));
+    case Expr::CALL: {
+      if (e->type == EVQL_T_BOOL) return 1.0;
+      std::vector<double> b;
+      for (const auto& a : e->args) b.push_back(expr_unsigned_bound(a, colmax));
+      switch (e->family) {
+        case EVQL_FAM_ADD: return b[0] + b[1];  // (< 2^53: exact in a double; larger sums
+        case EVQL_FAM_MUL: return b[0] * b[1];  //  are far beyond the 2^32 threshold)
+        case EVQL_FAM_MOD: case EVQL_FAM_DIV: return b[0];
+        default: return inf;
+      }
+    }
+    default:
+      return inf;
+  }
+}
+
+// Sets narrow_ident / narrow_first_row / AggPlan::narrow_arg from the maxima of the
+// referenced columns (one streaming pass per table column, cached): a member that
+// provably stays below 2^32 - 1 travels as 4 bytes through scatter / refine / aggregate.
+static Status choose_tuple_widths(evql_query* q) {
+  KernelPlan& kp = q->kp;
+  const double lim = 4294967295.0;  // strictly below: 32 ones are a minimum's identity
+  std::vector<double> colmax(kp.cols.size(), std::numeric_limits<double>::infinity());
+  for (size_t i = 0; i < colmax.size(); ++i) {
+    const ColAccess& c = kp.cols[i];
+    if (c.string_hash || (c.stype == EVQL_T_FLOAT64 && !c.from_uint_to_float)) continue;
+    if (c.stype != EVQL_T_UINT64 && c.stype != EVQL_T_TIMESTAMP64 && c.stype != EVQL_T_BOOL) continue;
+    Status st = column_abs_max(q, i, &colmax[i]);
+    if (!st.ok()) return st;
+  }
+  kp.narrow_ident = kp.key_mode == KEY_EXACT && expr_unsigned_bound(kp.group[0], colmax) < lim;
+  const uint64_t nrows = q->nested ? q->nested_rows : q->table->layout.num_rows;
+  kp.narrow_first_row = nrows < (1ull << 32);
+  for (auto& a : kp.aggs) {
+    a.narrow_arg = a.arg && expr_unsigned_bound(a.arg, colmax) < lim;
+  }
+  return Status();
+}
+
 static Status compile_plan_kernels(evql_query* q);
 
 static Status apply_where_resets(evql_query* q, const evql_table::LeafLevels& leaf);
@@ -1265,6 +1320,10 @@ Status query_finish(evql_query* q);
 // (re)compiles the fused kernel(s) of q->kp and sizes the persistent grid
 static Status compile_plan_kernels(evql_query* q) {
   evql_ctx* ctx = q->ctx;
+  if (q->kp.partitioned) {
+    Status stw = choose_tuple_widths(q);
+    if (!stw.ok()) return stw;
+  }
   q->source = generate_kernel_source(q->kp);
   Status st = compile_kernel(ctx, q->source, &q->module, true);
   if (!st.ok()) return st;
@@ -1566,8 +1625,7 @@ Status query_launch(evql_query* q) {
     HIP_TRY(launch_part_scan(q->d_part_counts, npart, nwg, q->d_bucket_start, s));
     uint64_t* d_total = q->d_bucket_start + npart + 1;
     HIP_TRY(launch_exclusive_scan(q->d_bucket_start, npart + 1, d_total, s));
-    const uint64_t tw = uint64_t(kp.first_row_word() + (kp.need_first_row ? 1 : 0)) +
-                        uint64_t(q->n_update_words);
+    const uint64_t tw = uint64_t(partition_tuple_u32_words(kp)) / 2;  // 8-byte words
     const uint64_t span = a.row_end - a.row_begin;
     uint64_t ntuples = span;  // upper bound: every row passes
     if (q->tuples_cap < span && span * tw * 8 > (16ull << 30)) {

@@ -120,6 +120,50 @@ def test_partitioned_high_cardinality_path(mixed):
     q.close()
 
 
+def test_partition_tuple_widths(mixed):
+    """tuple members that the table's column maxima bound below 2^32 travel as 4 bytes
+    through scatter / refine / aggregate (runtime.cc choose_tuple_widths): the layouts
+    the generator picks, and every narrow member kind against the oracle"""
+    import re
+    t, img, c = mixed
+
+    def u32_words(**kw):
+        q = t.query(Plan(T.MIXED_SCHEMA, groups_hint=3_000_000, **kw))
+        try:
+            return int(re.search(r"#define EVQL_TUPLE_U32 (\d+)", q.kernel_source()).group(1))
+        finally:
+            q.close()
+
+    a, b, k, w, v = col("a"), col("b"), col("k"), col("w"), col("v")
+    # key < 2^32, a < 2^32, float sum: 1 + 1 + 2 words (one 16-byte access per tuple)
+    assert u32_words(select=[b, sum_(a), count(1), sum_(v)], group_by=[b]) == 4
+    # 64-bit key values stay 8 bytes
+    assert u32_words(select=[w, sum_(a), count(1), sum_(v)], group_by=[w]) == 6
+    # a product that may pass 2^32 stays wide; a - b may wrap: wide
+    assert u32_words(select=[b, sum_(a * b * 4)], group_by=[b]) == 4   # 1 + 2, padded
+    assert u32_words(select=[b, sum_(a * 3)], group_by=[b]) == 2
+    assert u32_words(select=[b, sum_(a - b)], group_by=[b]) == 4
+    # hashed identity (2 x 2) + row (1) + narrow sum (1)
+    assert u32_words(select=[k, b, sum_(a)], group_by=[k, b]) == 6
+    for kw in (
+        dict(select=[b, sum_(a), min_(a), max_(a), min_(col("nb")), mean(a), count(1)], group_by=[b]),
+        dict(select=[b, sum_(a * 3 + 1), max_(a % 7), sum_(a * b), sum_(v)], group_by=[b], where=W),
+        dict(select=[a % 1000, min_(b), sum_(col("p")), max_(col("p"))], group_by=[a % 1000]),
+        dict(select=[b, col("s"), col("w"), max_(a)], group_by=[b]),
+        dict(select=[col("f"), b, min_(a), sum_(col("n"))], group_by=[col("f"), b], key_cols=2),
+    ):
+        kc = kw.pop("key_cols", 1)
+        for hint in (100_000, 3_000_000):
+            check(t, img, key_cols=kc, groups_hint=hint, **kw)
+    # exact float sums: the low 31 bits travel as 4 bytes
+    kw = dict(select=[b, sum_(v), sum_(a), count(1)], group_by=[b])
+    exp = O.oracle_run(img, Plan(T.MIXED_SCHEMA, **kw))
+    q = t.query(Plan(T.MIXED_SCHEMA, float_sum_mode=K.FLOAT_SUM_EXACT, groups_hint=3_000_000, **kw))
+    assert "evql_part_refine" in q.kernel_source()
+    T.compare_results(q.run().rows(), exp.rows(), exp.types, rel=1e-12)
+    q.close()
+
+
 def test_global_aggregates(mixed):
     t, img, _ = mixed
     check(t, img, key_cols=0, select=[count(1)])
