@@ -5,7 +5,12 @@
 #include <eventql/sql/qtree/SequentialScanNode.h>
 #include <eventql/sql/runtime/QueryBuilder.h>
 #include <eventql/sql/runtime/ValueExpression.h>
+#include <eventql/sql/runtime/query_cache.h>
+#include <eventql/sql/runtime/runtime.h>
 #include <eventql/util/exception.h>
+#include <eventql/util/io/inputstream.h>
+#include <eventql/util/io/outputstream.h>
+#include <eventql/util/stringutil.h>
 
 namespace evql_adapter {
 
@@ -29,11 +34,12 @@ GpuTableRegistry::~GpuTableRegistry() {
 }
 
 void GpuTableRegistry::registerTable(const std::string& table_name,
-                                     const std::string& cstable_file, ScanKind kind) {
+                                     const std::string& cstable_file, ScanKind kind,
+                                     const std::string& version_tag) {
   std::unique_lock<std::mutex> lk(mutex_);
   auto it = tables_.find(table_name);
   if (it != tables_.end() && it->second.table) evql_table_close(it->second.table);
-  tables_[table_name] = Entry{cstable_file, kind, nullptr};
+  tables_[table_name] = Entry{cstable_file, kind, nullptr, version_tag};
 }
 
 evql_ctx_t* GpuTableRegistry::context() {
@@ -48,7 +54,8 @@ evql_ctx_t* GpuTableRegistry::context() {
   return ctx_;
 }
 
-evql_table_t* GpuTableRegistry::lookup(const std::string& table_name, ScanKind* kind) {
+evql_table_t* GpuTableRegistry::lookup(const std::string& table_name, ScanKind* kind,
+                                       std::string* version_tag) {
   evql_ctx_t* ctx = context();
   if (!ctx) return nullptr;
   std::unique_lock<std::mutex> lk(mutex_);
@@ -65,6 +72,7 @@ evql_table_t* GpuTableRegistry::lookup(const std::string& table_name, ScanKind* 
     }
   }
   if (kind) *kind = it->second.kind;
+  if (version_tag) *version_tag = it->second.version_tag;
   return it->second.table;
 }
 
@@ -151,9 +159,18 @@ bool buildPlanDesc(csql::Transaction* txn, csql::GroupByNode* group,
 /* ----------------------------------------------------------------- operator */
 GpuGroupByScan::GpuGroupByScan(csql::Transaction* txn,
                                csql::ExecutionContext* execution_context, evql_query_t* query)
-    : txn_(txn), execution_context_(execution_context), query_(query), completed_(false) {
+    : txn_(txn), execution_context_(execution_context), query_(query), completed_(false),
+      from_cache_(false), recording_(false), recorded_bytes_(0), replay_pos_(0) {
   execution_context_->incrementNumTasks(); /* groupby.cc:54 */
 }
+
+void GpuGroupByScan::enableQueryCache(const SHA1Hash& key,
+                                      std::shared_ptr<std::atomic<uint64_t>> hit_counter) {
+  cache_key_ = Some(key);
+  cache_hits_ = hit_counter;
+}
+
+Option<SHA1Hash> GpuGroupByScan::getCacheKey() const { return cache_key_; }
 
 GpuGroupByScan::~GpuGroupByScan() { evql_query_destroy(query_); }
 
@@ -164,6 +181,37 @@ int GpuGroupByScan::heartbeat(void* self) {
 
 ReturnCode GpuGroupByScan::execute() {
   execution_context_->incrementNumTasksRunning(); /* groupby.cc:70 */
+  /* read cache (groupby.cc:255-296).  The entry holds this operator's own output
+   * batches -- packed SVector bytes per column -- not the CPU operator's group map:
+   * the key is salted ("~mi355x", GpuScheduler::tryLower) so the two never mix. */
+  csql::QueryCache* cache = cache_key_.isEmpty() ? nullptr : txn_->getRuntime()->getQueryCache();
+  if (cache) {
+    cache->getEntry(cache_key_.get(), [this](InputStream* is) {
+      if (is->readUInt8() != 0x02) return;
+      uint64_t nbatches = is->readUInt64();
+      uint64_t ncols = is->readUInt64();
+      if (ncols != getColumnCount()) return;
+      std::vector<CachedBatch> got;
+      for (uint64_t b = 0; b < nbatches; ++b) {
+        CachedBatch cb;
+        cb.nrows = is->readUInt64();
+        for (uint64_t c = 0; c < ncols; ++c) {
+          uint64_t sz = is->readUInt64();
+          std::string bytes(sz, 0);
+          if (sz) is->readNextBytes(&bytes[0], sz);
+          cb.columns.emplace_back(std::move(bytes));
+        }
+        got.emplace_back(std::move(cb));
+      }
+      batches_ = std::move(got);
+      from_cache_ = true;
+    });
+    if (from_cache_) {
+      if (cache_hits_) cache_hits_->fetch_add(1);
+      return ReturnCode::success();
+    }
+    recording_ = true;
+  }
   int rc = evql_query_execute(query_, &GpuGroupByScan::heartbeat, this);
   if (rc != EVQL_OK) {
     return ReturnCode::error(statusCodeString(rc), evql_last_error());
@@ -173,6 +221,20 @@ ReturnCode GpuGroupByScan::execute() {
 
 ReturnCode GpuGroupByScan::nextBatch(csql::SVector* columns, size_t* len) {
   size_t ncols = getColumnCount();
+  if (from_cache_) {
+    *len = 0;
+    if (replay_pos_ < batches_.size()) {
+      const CachedBatch& cb = batches_[replay_pos_++];
+      for (size_t i = 0; i < ncols; ++i) {
+        if (!cb.columns[i].empty()) columns[i].append(cb.columns[i].data(), cb.columns[i].size());
+      }
+      *len = cb.nrows;
+    } else if (!completed_) {
+      completed_ = true;
+      execution_context_->incrementNumTasksCompleted();
+    }
+    return ReturnCode::success();
+  }
   std::vector<evql_column_buf_t> bufs(ncols);
   int rc = evql_query_next_batch(query_, kOutputBatchSize, bufs.data(), len);
   if (rc != EVQL_OK) {
@@ -182,9 +244,40 @@ ReturnCode GpuGroupByScan::nextBatch(csql::SVector* columns, size_t* len) {
     /* the library hands out packed SVector elements (svalue.cc:410-517) */
     if (bufs[i].size > 0) columns[i].append(bufs[i].data, bufs[i].size);
   }
+  if (recording_ && *len > 0) {
+    CachedBatch cb;
+    cb.nrows = *len;
+    for (size_t i = 0; i < ncols; ++i) {
+      cb.columns.emplace_back(reinterpret_cast<const char*>(bufs[i].data), bufs[i].size);
+      recorded_bytes_ += bufs[i].size;
+    }
+    batches_.emplace_back(std::move(cb));
+    if (recorded_bytes_ > kMaxCachedBytes) { /* too large to be worth a cache file */
+      recording_ = false;
+      batches_.clear();
+    }
+  }
   if (*len == 0 && !completed_) {
     completed_ = true;
     execution_context_->incrementNumTasksCompleted(); /* groupby.cc:211 */
+    /* store cache (groupby.cc:410-432) once the consumer has drained the operator */
+    csql::QueryCache* cache = recording_ ? txn_->getRuntime()->getQueryCache() : nullptr;
+    if (cache) {
+      cache->storeEntry(cache_key_.get(), [this, ncols](OutputStream* os) {
+        os->appendUInt8(0x02);
+        os->appendUInt64(batches_.size());
+        os->appendUInt64(ncols);
+        for (const auto& cb : batches_) {
+          os->appendUInt64(cb.nrows);
+          for (const auto& c : cb.columns) {
+            os->appendUInt64(c.size());
+            if (!c.empty()) os->write(c.data(), c.size());
+          }
+        }
+      });
+    }
+    recording_ = false;
+    batches_.clear();
   }
   return ReturnCode::success();
 }
@@ -199,7 +292,7 @@ csql::SType GpuGroupByScan::getColumnType(size_t idx) const {
 
 /* ---------------------------------------------------------------- scheduler */
 GpuScheduler::GpuScheduler(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts)
-    : tables_(tables), opts_(opts) {}
+    : tables_(tables), opts_(opts), cache_hits_(new std::atomic<uint64_t>(0)) {}
 
 csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
                                               csql::ExecutionContext* execution_context,
@@ -207,7 +300,8 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
                                               csql::SequentialScanNode* seqscan,
                                               std::string* why) {
   ScanKind kind = ScanKind::FAST;
-  evql_table_t* table = tables_->lookup(seqscan->tableName(), &kind);
+  std::string version_tag;
+  evql_table_t* table = tables_->lookup(seqscan->tableName(), &kind, &version_tag);
   if (!table) {
     *why = tables_->lastError();
     return nullptr;
@@ -230,7 +324,32 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
      * column type, CSTableScan.cc:783-784) */
     RAISE(kRuntimeError, evql_last_error());
   }
-  return new GpuGroupByScan(txn, execution_context, q);
+  auto op = new GpuGroupByScan(txn, execution_context, q);
+  if (partial && !version_tag.empty()) {
+    /* PartialGroupByExpression::getCacheKey = SHA1(input key + fingerprint of the
+     * group-by's expressions) (groupby.cc:474-482, server/sql/scheduler.cc:85-103);
+     * the input's key = SHA1 over the scan's select list + WHERE and the table
+     * version (server/sql/table_provider.cc:216-238) */
+    SHA1Hash scan_fp;
+    for (const auto& sl : seqscan->selectList()) {
+      scan_fp = SHA1::compute(scan_fp.toString() + sl->toString());
+    }
+    if (!seqscan->whereExpression().isEmpty()) {
+      scan_fp = SHA1::compute(scan_fp.toString() + seqscan->whereExpression().get()->toString());
+    }
+    SHA1Hash scan_key =
+        SHA1::compute(StringUtil::format("$0~$1~$2", "", scan_fp.toString(), version_tag));
+    SHA1Hash group_fp;
+    for (const auto& sl : group->selectList()) {
+      group_fp = SHA1::compute(group_fp.toString() + sl->toString());
+    }
+    for (const auto& e : group->groupExpressions()) {
+      group_fp = SHA1::compute(group_fp.toString() + e->toString());
+    }
+    op->enableQueryCache(
+        SHA1::compute(scan_key.toString() + group_fp.toString() + "~mi355x"), cache_hits_);
+  }
+  return op;
 }
 
 ScopedPtr<csql::TableExpression> GpuScheduler::buildGroupByExpression(

@@ -16,6 +16,7 @@
  *   FastCSTableScan / CSTableScan (replaced) sql/CSTableScan.cc:187-541, 688-1009
  */
 #pragma once
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -24,6 +25,8 @@
 #include <eventql/sql/scheduler.h>
 #include <eventql/sql/table_expression.h>
 #include <eventql/sql/transaction.h>
+#include <eventql/util/SHA1.h>
+#include <eventql/util/option.h>
 #include "evql_gpu.h"
 #include "gpu_bridge.h"
 
@@ -48,12 +51,16 @@ public:
   ~GpuTableRegistry();
   GpuTableRegistry(const GpuTableRegistry&) = delete;
 
+  /* version_tag: what identifies this file's contents to the query cache -- the
+   * "$namespace~$table~$partition~$lsm_sequence" ingredients of TableScan's cache key
+   * (server/sql/table_provider.cc:229-238).  Empty: results are never cached. */
   void registerTable(const std::string& table_name, const std::string& cstable_file,
-                     ScanKind kind = ScanKind::FAST);
+                     ScanKind kind = ScanKind::FAST, const std::string& version_tag = "");
 
   /* opens (once) and returns the resident table; nullptr when the name is unknown
    * or no device is present -- the caller then keeps the CPU operators */
-  evql_table_t* lookup(const std::string& table_name, ScanKind* kind);
+  evql_table_t* lookup(const std::string& table_name, ScanKind* kind,
+                       std::string* version_tag = nullptr);
   evql_ctx_t* context();
   const std::string& lastError() const { return last_error_; }
 
@@ -62,6 +69,7 @@ private:
     std::string file;
     ScanKind kind;
     evql_table_t* table;
+    std::string version_tag;
   };
   std::mutex mutex_;
   int device_;
@@ -102,12 +110,30 @@ public:
   size_t getColumnCount() const override;
   csql::SType getColumnType(size_t idx) const override;
 
+  /* PartialGroupByExpression's twin keeps its rows in the runtime's QueryCache under
+   * this key, like the operator it replaces (groupby.cc:255-296, 410-432, 474-482);
+   * hits are counted in *hit_counter when given */
+  void enableQueryCache(const SHA1Hash& key, std::shared_ptr<std::atomic<uint64_t>> hit_counter);
+  Option<SHA1Hash> getCacheKey() const override;
+
 private:
   static int heartbeat(void* self);
+  static const size_t kMaxCachedBytes = 256u << 20;
+  struct CachedBatch {
+    size_t nrows;
+    std::vector<std::string> columns; /* packed SVector bytes */
+  };
   csql::Transaction* txn_;
   csql::ExecutionContext* execution_context_;
   evql_query_t* query_;
   bool completed_;
+  Option<SHA1Hash> cache_key_;
+  std::shared_ptr<std::atomic<uint64_t>> cache_hits_;
+  bool from_cache_;
+  bool recording_;
+  size_t recorded_bytes_;
+  size_t replay_pos_;
+  std::vector<CachedBatch> batches_;
 };
 
 struct GpuSchedulerOptions {
@@ -131,6 +157,7 @@ public:
   };
   const std::vector<Decision>& decisions() const { return decisions_; }
   void clearDecisions() { decisions_.clear(); }
+  uint64_t queryCacheHits() const { return cache_hits_->load(); }
 
 protected:
   ScopedPtr<csql::TableExpression> buildGroupByExpression(
@@ -150,6 +177,7 @@ protected:
   std::shared_ptr<GpuTableRegistry> tables_;
   GpuSchedulerOptions opts_;
   std::vector<Decision> decisions_;
+  std::shared_ptr<std::atomic<uint64_t>> cache_hits_;
 };
 
 const char* statusCodeString(int evql_status_code);

@@ -19,7 +19,9 @@
  *   * bench.py's cpu_baseline leg (kind "reference") times the CPU operators.
  *
  * Protocol: commands on stdin, one per line; one JSON line per SQL on stdout.
- *   TABLE <name> <file.cst> [fast|dremel]   register a table (provider + GPU registry)
+ *   TABLE <name> <file.cst> [fast|dremel] [version tag]  register a table (provider + GPU
+ *                                           registry; a tag makes partial results cacheable)
+ *   CACHE <dir>                             install a csql::QueryCache (stores at first use)
  *   MODE cpu|gpu|gpuscan [partial] [strict] which operators execute
  *   DUMP on|off                             include the compiled programs
  *   ROWS on|off                             include result rows (off: count only)
@@ -43,6 +45,7 @@
 #include <eventql/sql/qtree/SequentialScanNode.h>
 #include <eventql/sql/result_cursor.h>
 #include <eventql/sql/runtime/defaultruntime.h>
+#include <eventql/sql/runtime/query_cache.h>
 #include <eventql/sql/runtime/runtime.h>
 #include <eventql/sql/runtime/tablerepository.h>
 #include <eventql/sql/statements/select/groupby.h>
@@ -384,6 +387,7 @@ struct Probe {
         first = false;
       }
       o << "]";
+      o << ",\"query_cache_hits\":" << scheduler->queryCacheHits();
     }
     return o.str();
   }
@@ -430,6 +434,8 @@ int main(int argc, char** argv) {
       Probe::Tbl t;
       is >> t.name >> t.file;
       if (!(is >> t.kind)) t.kind = "fast";
+      std::string tag;
+      is >> tag;
       bool replaced = false;
       for (auto& e : probe.tables) {
         if (e.name == t.name) {
@@ -439,7 +445,12 @@ int main(int argc, char** argv) {
       }
       if (!replaced) probe.tables.push_back(t);
       probe.registry->registerTable(t.name, t.file,
-                                    t.kind == "dremel" ? ScanKind::DREMEL : ScanKind::FAST);
+                                    t.kind == "dremel" ? ScanKind::DREMEL : ScanKind::FAST, tag);
+    } else if (cmd == "CACHE") {
+      std::string dir;
+      is >> dir;
+      /* (lives as long as the process, like evqld's) */
+      probe.runtime->setQueryCache(new csql::QueryCache(dir, 8192, 0));
     } else if (cmd == "MODE") {
       is >> g_state.mode;
       g_state.partial = g_state.strict = false;

@@ -172,3 +172,38 @@ def test_reference_engine_with_gpu_operator(suite):
                 assert sqlgen.rows_digest(rows) == want["digest"], c["id"]
     # the GPU operator, not the CPU fallback, produced (most of) these
     assert lowered >= (0.9 if suite != "nested" else 0.3) * len(cases), (lowered, len(cases))
+
+
+@pytest.mark.skipif(not os.path.exists(PROBE), reason="oracle/_ref/csql_probe not built "
+                    "(needs /root/reference at build time)")
+def test_partial_operator_uses_the_query_cache():
+    """PartialGroupByExpression keeps its groups in the runtime's QueryCache under
+    getCacheKey() (groupby.cc:255-296, 410-432, 474-482); so does its GPU twin: the
+    second run of a query is served from the cache file, byte for byte, another query
+    or another table version is not"""
+    img, _, kind = refcases.table_image("survey")
+    q1 = "select k, sum(a), count(1) from t where a > 30000 group by k;"
+    q2 = "select k, sum(a), count(1) from t where a > 20000 group by k;"
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "t.cst")
+        with open(path, "wb") as f:
+            f.write(img)
+        cache = os.path.join(tmp, "qc")
+        os.mkdir(cache)
+        cmds = ["TABLE t %s %s ns~t~p0~17" % (path, kind), "CACHE " + cache, "ROWS on",
+                "MODE gpu partial strict", "SQL " + q1, "SQL " + q1, "SQL " + q2, "SQL " + q1,
+                "TABLE t %s %s ns~t~p0~18" % (path, kind), "SQL " + q1,
+                "TABLE t %s %s" % (path, kind), "SQL " + q1]
+        p = subprocess.run([PROBE], input="\n".join(cmds) + "\n", capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res = [json.loads(l) for l in p.stdout.splitlines() if l.strip()]
+        assert all(r["ok"] for r in res), [r.get("error") for r in res]
+        # hits are counted per scheduler (= since "MODE"): miss, hit, miss, hit, miss, -
+        assert [r["query_cache_hits"] for r in res] == [0, 1, 1, 2, 2, 2]
+        assert len(os.listdir(cache)) == 3
+        base = probe_rows(res[0])
+        assert len(base) == 1000
+        for r in (res[1], res[3], res[4], res[5]):
+            assert probe_rows(r) == base
+        assert probe_rows(res[2]) != base
