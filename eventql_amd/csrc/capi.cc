@@ -19,6 +19,7 @@ Status query_finish(evql_query* q);
 Status query_reset(evql_query* q);
 Status query_recount(evql_query* q);
 Status query_dense_into_table(evql_query* q);
+Status query_reserve_groups(evql_query* q, uint64_t extra);
 Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n, int64_t limit,
                        uint64_t offset);
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows);
@@ -675,30 +676,34 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   hipStream_t s = q->ctx->stream;
   {
-    Status st = query_dense_into_table(q);
+    // (also moves the dense records of the partitioned path into the table)
+    Status st = query_reserve_groups(q, n_groups);
     if (!st.ok()) return ret(st);
   }
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    MergeArgs a{};
-    a.words = q->d_gtab;
-    a.gcap = q->gcap;
-    a.stride = q->gcap + 8;
-    a.nwords = uint32_t(q->kp.words_per_slot());
-    int w = 1;
-    a.has_ident2 = q->kp.has_ident2() ? 1 : 0;
-    if (q->kp.has_ident2()) a.ops[w++] = 255;
-    if (q->kp.need_first_row) a.ops[w++] = 2;  // min
-    for (const auto& sw : q->kp.states) a.ops[w++] = uint32_t(sw.op);
-    a.status = q->d_status;
-    hipMemsetAsync(q->d_status, 0, 16, s);
-    hipError_t e = launch_table_merge(a, static_cast<const uint64_t*>(device_src), n_groups, s);
-    uint32_t status[4] = {0};
-    hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-      return fail(EVQL_EDEVICE, "merge kernel failed");
-    }
-    if (!(status[0] & 2u)) break;
-    return fail(EVQL_ENOMEM, "group table full during merge; raise groups_hint");
+  MergeArgs a{};
+  a.words = q->d_gtab;
+  a.gcap = q->gcap;
+  a.stride = q->gcap + 8;
+  a.nwords = uint32_t(q->kp.words_per_slot());
+  int w = 1;
+  a.has_ident2 = q->kp.has_ident2() ? 1 : 0;
+  if (q->kp.has_ident2()) a.ops[w++] = 255;
+  if (q->kp.need_first_row) a.ops[w++] = 2;  // min
+  for (const auto& sw : q->kp.states) a.ops[w++] = uint32_t(sw.op);
+  a.status = q->d_status;
+  hipMemsetAsync(q->d_status, 0, 16, s);
+  hipError_t e = launch_table_merge(a, static_cast<const uint64_t*>(device_src), n_groups, s);
+  uint32_t status[4] = {0};
+  hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    return fail(EVQL_EDEVICE, "merge kernel failed");
+  }
+  if (status[0] & 2u) {
+    // cannot happen for capacity (reserved above); a probe chain beyond the bound would
+    // leave the merge half done, so the aggregate is unusable from here on
+    q->executed = false;
+    q->ngroups = 0;
+    return fail(EVQL_ENOMEM, "group table probe bound exceeded during merge; the query must be re-run");
   }
   // the host copy of the result (if any) is stale now
   return ret(query_recount(q));

@@ -1765,15 +1765,15 @@ Status query_recount(evql_query* q) {
   return Status();
 }
 
-// the dense records of the partitioned path moved into the (regrown) HBM hash table:
-// what merging another partition's groups into this query needs
-Status query_dense_into_table(evql_query* q) {
-  if (q->dense_n == 0) return Status();
+// Moves every group of the query -- slots of the HBM hash table and the dense records of
+// the partitioned path -- into a fresh hash table with room for `total` groups at load
+// factor <= 1/2.
+static Status rebuild_table(evql_query* q, uint64_t total) {
   evql_ctx* ctx = q->ctx;
   hipStream_t s = ctx->stream;
   const KernelPlan& kp = q->kp;
   const uint32_t nwords = uint32_t(kp.words_per_slot());
-  // groups already in the table (overflowed buckets)
+  // groups already in the table (overflowed buckets of the partitioned path, or all)
   uint64_t in_table = q->ngroups - q->dense_n;
   DevBuf<uint64_t> old_rec;
   if (in_table) {
@@ -1784,7 +1784,7 @@ Status query_dense_into_table(evql_query* q) {
     HIP_TRY(hipStreamSynchronize(s));
   }
   uint64_t cap = 1 << 16;
-  while (cap < q->ngroups * 2) cap <<= 1;
+  while (cap < total * 2) cap <<= 1;
   Status st = alloc_gtab(q, cap);
   if (!st.ok()) return st;
   TableInitArgs ia{};
@@ -1810,13 +1810,27 @@ Status query_dense_into_table(evql_query* q) {
   a.status = q->d_status;
   HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
   if (in_table) HIP_TRY(launch_table_merge(a, old_rec, in_table, s));
-  HIP_TRY(launch_table_merge(a, q->d_dense, q->dense_n, s));
+  if (q->dense_n) HIP_TRY(launch_table_merge(a, q->d_dense, q->dense_n, s));
   uint32_t status[4] = {0};
   HIP_TRY(hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (status[0] & 2u) return Status::error(EVQL_ENOMEM, "group table full");
   q->dense_n = 0;
   return Status();
+}
+
+// the dense records of the partitioned path moved into the (regrown) HBM hash table:
+// what merging another partition's groups into this query needs
+Status query_dense_into_table(evql_query* q) {
+  if (q->dense_n == 0) return Status();
+  return rebuild_table(q, q->ngroups);
+}
+
+// room for `extra` more groups: the table is rebuilt BEFORE a merge could fill it, so a
+// merge never stops half way (GroupByMergeExpression's map simply grows, groupby.cc:528-637)
+Status query_reserve_groups(evql_query* q, uint64_t extra) {
+  if (q->dense_n == 0 && (q->ngroups + extra) * 2 <= q->gcap) return Status();
+  return rebuild_table(q, q->ngroups + extra);
 }
 
 // (re)creates an empty group table without scanning: the merge target of

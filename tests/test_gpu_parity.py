@@ -344,6 +344,43 @@ def test_row_ranges_partition_the_table(mixed):
     qb.close()
 
 
+def test_import_grows_the_group_table(mixed):
+    """a merge target never fills up half way (GroupByMergeExpression's map just grows,
+    groupby.cc:528-637): the table is rebuilt with room for the incoming groups first --
+    here 8 slices of ~37,000 distinct 64-bit keys each into a table that started with
+    65,536 slots, and into an empty `reset` target"""
+    import torch
+    t, img, _ = mixed
+    n, parts = 300_000, 8
+    kw = dict(select=[col("w"), count(1), sum_(col("a")), min_(col("b"))], group_by=[col("w")])
+    exp = O.oracle_run(img, Plan(T.MIXED_SCHEMA, **kw))
+    cut = [n * i // parts for i in range(parts + 1)]
+    qs = [t.query(Plan(T.MIXED_SCHEMA, row_begin=cut[i], row_end=cut[i + 1], groups_hint=1000, **kw))
+          for i in range(parts)]
+    for q in qs:
+        q.execute()
+    rw = qs[0].record_words()
+    buf = torch.zeros(60_000 * rw, dtype=torch.int64, device="cuda")
+    target = t.query(Plan(T.MIXED_SCHEMA, groups_hint=1000, **kw))
+    target.reset()
+    for dst in (qs[0], target):
+        for q in qs[1:]:
+            cnt = q.export_groups(buf.data_ptr(), 60_000)
+            dst.import_groups(buf.data_ptr(), cnt)
+    # qs[0] now holds everything; target holds slices 1..7 -- add slice 0 through a fresh
+    # scan of that range
+    q0 = t.query(Plan(T.MIXED_SCHEMA, row_begin=cut[0], row_end=cut[1], groups_hint=1000, **kw))
+    q0.execute()
+    cnt = q0.export_groups(buf.data_ptr(), 60_000)
+    target.import_groups(buf.data_ptr(), cnt)
+    for dst in (qs[0], target):
+        got = dst.fetch_all(1 << 20)
+        assert got.nrows == exp.nrows
+        T.compare_results(got.rows(), exp.rows(), exp.types)
+    for q in qs + [target, q0]:
+        q.close()
+
+
 def test_partial_group_by_wire_rows(mixed):
     """EVQL_MODE_PARTIAL = PartialGroupByExpression::nextBatch (groupby.cc:438-472):
     (SHA1 group key, concatenated saved states / encoded SValues), byte for byte"""
