@@ -71,6 +71,9 @@ def lib():
     L.evql_table_from_device_columns.argtypes = [C.c_void_p, C.POINTER(K.ColumnSpec), C.c_int,
                                                  C.POINTER(K.DeviceColumn), C.c_uint64,
                                                  C.POINTER(C.c_void_p)]
+    L.evql_table_from_device_columns_ordered.argtypes = [
+        C.c_void_p, C.POINTER(K.ColumnSpec), C.c_int, C.POINTER(K.DeviceColumn), C.c_uint64,
+        C.c_int, C.POINTER(C.c_void_p)]
     L.evql_writer_create.argtypes = [C.POINTER(K.ColumnSpec), C.c_int, C.POINTER(C.c_void_p)]
     L.evql_writer_put_uint.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p, _u64p]
     L.evql_writer_put_float.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _u64p, _u64p, _u8p, _f64p]
@@ -278,14 +281,14 @@ class Context:
         return Table(self, t)
 
     def table_from_device_columns(self, columns, values, nulls, num_rows, heaps=None,
-                                  levels=None):
+                                  levels=None, page_order=0):
         """evql_table_from_device_columns: `columns` as for Writer; values[name] /
         nulls[name] are DEVICE addresses (e.g. torch tensor .data_ptr()) of num_rows
         u64 value words / NULL-flag bytes (nulls only for optional columns);
         heaps[name]: byte heap of a STRING_PLAIN column, whose value words are
         (length << 40) | offset into it; levels[name] = (rlevels address | None,
         dlevels address, num_slots) for a repeated / nested column, whose values are
-        given per slot"""
+        given per slot; page_order: capi.PAGE_ORDER_COLUMNS / PAGE_ORDER_ROWS"""
         names = [c["name"].encode() for c in columns]
         specs = (K.ColumnSpec * len(columns))()
         data = (K.DeviceColumn * len(columns))()
@@ -297,8 +300,8 @@ class Context:
             data[i] = K.DeviceColumn(values[c["name"]], (nulls or {}).get(c["name"]),
                                      (heaps or {}).get(c["name"]), rl, dl, ns)
         t = C.c_void_p()
-        _check(lib().evql_table_from_device_columns(self.h, specs, len(columns), data, num_rows,
-                                                    C.byref(t)))
+        _check(lib().evql_table_from_device_columns_ordered(self.h, specs, len(columns), data,
+                                                            num_rows, page_order, C.byref(t)))
         return Table(self, t)
 
     def close(self):

@@ -195,5 +195,6 @@ class Transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_gather_u64", ALL_GATHER_FN),
                 ("all_to_all_words", ALL_TO_ALL_FN), ("name", C.c_char_p)]
 
+PAGE_ORDER_COLUMNS, PAGE_ORDER_ROWS = 0, 1
 FLOAT_SUM_FAST = 0
 FLOAT_SUM_EXACT = 1

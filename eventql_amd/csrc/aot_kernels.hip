@@ -1882,6 +1882,99 @@ __global__ void __launch_bounds__(kBlock) k_wr_str_emit(u8* image, const u64* pa
 
 }  // namespace
 
+// ---- page placement queries (device_writer.cc: in which order the reference's page
+// writers would have allocated their pages).  Few queries (one per page), one thread each:
+// a binary search over the scanned per-tile counts, then a walk inside one 2048-entry tile.
+// select: position of the q-th (0-based) zero byte of flags[0..n)
+__global__ void __launch_bounds__(kBlock) k_wr_select_zero(const u8* flags, u64 n,
+                                                           const u64* tile_offsets, u64 ntiles,
+                                                           const u64* queries, u64 nq, u64* out) {
+  const u64 qi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  const u64 q = queries[qi];
+  u64 lo = 0, hi = ntiles;  // last tile whose offset is <= q
+  while (hi - lo > 1) {
+    const u64 mid = (lo + hi) / 2;
+    if (tile_offsets[mid] <= q) lo = mid; else hi = mid;
+  }
+  u64 seen = tile_offsets[lo];
+  u64 pos = n;
+  for (u64 i = lo * kDecodeTile; i < n && i < (lo + 1) * kDecodeTile; ++i) {
+    if (flags[i] == 0) {
+      if (seen == q) { pos = i; break; }
+      ++seen;
+    }
+  }
+  out[qi] = pos;
+}
+
+// rank: number of zero bytes in flags[0..q] (inclusive)
+__global__ void __launch_bounds__(kBlock) k_wr_rank_zero(const u8* flags, u64 n,
+                                                         const u64* tile_offsets,
+                                                         const u64* queries, u64 nq, u64* out) {
+  const u64 qi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  u64 q = queries[qi];
+  if (q >= n) q = n - 1;
+  const u64 t = q / kDecodeTile;
+  u64 cnt = tile_offsets[t];
+  for (u64 i = t * kDecodeTile; i <= q; ++i) cnt += flags[i] == 0 ? 1 : 0;
+  out[qi] = cnt;
+}
+
+// the value whose encoding holds byte q of a LEB128 / STRING_PLAIN stream
+__global__ void __launch_bounds__(kBlock) k_wr_select_byte(const u64* dense, u64 n,
+                                                           const u64* chunk_offsets, u64 nchunks,
+                                                           u32 is_string, const u64* queries,
+                                                           u64 nq, u64* out) {
+  const u64 qi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  const u64 q = queries[qi];
+  u64 lo = 0, hi = nchunks;
+  while (hi - lo > 1) {
+    const u64 mid = (lo + hi) / 2;
+    if (chunk_offsets[mid] <= q) lo = mid; else hi = mid;
+  }
+  u64 pos = chunk_offsets[lo];
+  u64 idx = n;
+  for (u64 i = lo * kDecodeTile; i < n && i < (lo + 1) * kDecodeTile; ++i) {
+    const u64 len = is_string ? wr_str_size(dense[i]) : wr_leb_len(dense[i]);
+    if (q < pos + len) { idx = i; break; }
+    pos += len;
+  }
+  out[qi] = idx;
+}
+
+hipError_t launch_wr_select_zero(const uint8_t* flags, uint64_t n, const uint64_t* tile_offsets,
+                                 const uint64_t* queries, uint64_t nq, uint64_t* out, hipStream_t s) {
+  const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
+  if (nq == 0 || ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_select_zero, dim3((unsigned) ((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     s, flags, (u64) n, (const u64*) tile_offsets, ntiles, (const u64*) queries,
+                     (u64) nq, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_rank_zero(const uint8_t* flags, uint64_t n, const uint64_t* tile_offsets,
+                               const uint64_t* queries, uint64_t nq, uint64_t* out, hipStream_t s) {
+  if (nq == 0 || n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_rank_zero, dim3((unsigned) ((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     s, flags, (u64) n, (const u64*) tile_offsets, (const u64*) queries, (u64) nq,
+                     (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_wr_select_byte(const uint64_t* dense, uint64_t n, const uint64_t* chunk_offsets,
+                                 bool is_string, const uint64_t* queries, uint64_t nq,
+                                 uint64_t* out, hipStream_t s) {
+  const u64 nchunks = (n + kDecodeTile - 1) / kDecodeTile;
+  if (nq == 0 || nchunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wr_select_byte, dim3((unsigned) ((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     s, (const u64*) dense, (u64) n, (const u64*) chunk_offsets, nchunks,
+                     is_string ? 1u : 0u, (const u64*) queries, (u64) nq, (u64*) out);
+  return hipGetLastError();
+}
+
 hipError_t launch_wr_count_defined(const uint8_t* nulls, uint64_t nrows, uint64_t* tile_counts,
                                    hipStream_t s) {
   const u64 ntiles = (nrows + kDecodeTile - 1) / kDecodeTile;

@@ -372,8 +372,19 @@ int evql_table_generate(evql_ctx_t* ctx, const evql_synth_spec_t* spec, evql_tab
 int evql_table_from_device_columns(evql_ctx_t* ctx, const evql_column_spec_t* cols, int ncols,
                                    const evql_device_column_t* data, uint64_t num_rows,
                                    evql_table_t** out) {
+  return evql_table_from_device_columns_ordered(ctx, cols, ncols, data, num_rows,
+                                                EVQL_PAGE_ORDER_COLUMNS, out);
+}
+
+int evql_table_from_device_columns_ordered(evql_ctx_t* ctx, const evql_column_spec_t* cols,
+                                           int ncols, const evql_device_column_t* data,
+                                           uint64_t num_rows, int page_order,
+                                           evql_table_t** out) {
   API_TRY
   if (!ctx || !cols || !data || !out || ncols <= 0) return fail(EVQL_EARG, "bad arguments");
+  if (page_order != EVQL_PAGE_ORDER_COLUMNS && page_order != EVQL_PAGE_ORDER_ROWS) {
+    return fail(EVQL_EARG, "bad page order");
+  }
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
   std::vector<ColumnSpec> specs;
   std::vector<DeviceColumnIn> in;
@@ -395,7 +406,7 @@ int evql_table_from_device_columns(evql_ctx_t* ctx, const evql_column_spec_t* co
                   data[i].num_slots});
   }
   evql_table* t = nullptr;
-  Status st = table_from_device_columns(ctx, specs, in, num_rows, &t);
+  Status st = table_from_device_columns(ctx, specs, in, num_rows, page_order, &t);
   if (!st.ok()) return ret(st);
   *out = t;
   return EVQL_OK;

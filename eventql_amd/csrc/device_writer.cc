@@ -9,13 +9,19 @@
 // `evql_table_download_image` yields the file bytes.
 //
 // Page placement: PageManager::allocPage (page_manager.cc:50-74) hands out pages
-// at the running file offset in the order streams first need them, so the byte
-// layout of a reference-written file depends on how rows of different columns
-// interleave.  This writer lays a column's definition-level pages down first,
-// then its data pages, column after column -- what the host writer
-// (cstable_format.cc TableWriter, one whole column per `put`) produces whenever
-// each stream of an optional column fits one page, and exactly for required
-// columns of any size.  Readers follow the page index, so every order is valid.
+// at the running file offset in the order the page writers first need them, so the
+// byte layout of a reference-written file depends on the order of the write calls.
+// Both orders a caller of the reference can produce are reproduced byte for byte:
+//   EVQL_PAGE_ORDER_COLUMNS  one whole column after the other (what cstable_format.cc's
+//                            TableWriter and a ColumnWriter-per-column loop produce)
+//   EVQL_PAGE_ORDER_ROWS     row by row, every column per row in schema order
+//                            (RecordShredder::addRecord*, cstable_writer.cc addRow loops)
+// A page is allocated by the write that first does not fit: level page k (bit-packed,
+// 131,072 values) at slot 131,072 k; a fixed-width data page at its first value; a
+// LEB128 / string page by the value whose encoding holds stream byte 524,288 k.  Those
+// value indexes are found on the device (k_wr_select_byte), mapped to the slot / record
+// that writes them (k_wr_select_zero over the NULL flags, k_wr_rank_zero over the
+// repetition levels) and the allocations sorted on the host -- a few thousand entries.
 //
 // Repeated / nested columns arrive shredded, one (r, d, value) triple per slot: their
 // level streams are bit-packed from the level arrays and the values of the slots with
@@ -26,6 +32,7 @@
 // which the scan side names a string of a resident table (MaterializedColumn::d_strpos)
 // -- and are encoded like LEB128 streams: sizes per 2048-value chunk, scan, bytes at
 // their stream positions.
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include "runtime.h"
@@ -53,6 +60,18 @@ struct ColumnWork {
   DevBuf<uint64_t> chunk_offsets;   // LEB128: scanned bytes per 2048-value chunk
   uint64_t leb_bytes = 0;
   uint32_t bits = 0;                // bit-packed data stream width
+  DevBuf<uint64_t> def_tiles;       // scanned per-tile counts of the defined slots
+};
+
+// one PageManager::allocPage call of the sequential writer
+struct PageAlloc {
+  uint64_t record;  // row / record whose write allocates the page (ROWS order)
+  uint64_t slot;    // slot of that column (value position incl. NULLs)
+  uint32_t column;
+  uint32_t stream;  // 0 repetition levels, 1 definition levels, 2 data (the order of
+                    // ColumnWriter::write*, ColumnWriter.cc:59-89)
+  uint32_t page;    // index within the stream
+  uint32_t size;
 };
 
 void put_varuint(std::vector<uint8_t>* b, uint64_t v) {
@@ -67,7 +86,7 @@ void put_varuint(std::vector<uint8_t>* b, uint64_t v) {
 
 Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& specs,
                                  const std::vector<DeviceColumnIn>& in, uint64_t n,
-                                 evql_table** out) {
+                                 int page_order, evql_table** out) {
   hipStream_t s = ctx->stream;
   std::vector<ColumnWork> work(specs.size());
 
@@ -112,7 +131,7 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
     }
     if (c.dlevel_max > 0 && w.nslots) {
       const uint64_t nt = (w.nslots + kDecodeTile - 1) / kDecodeTile;
-      DevBuf<uint64_t> d_tiles;
+      DevBuf<uint64_t>& d_tiles = w.def_tiles;
       HIP_TRY(d_tiles.alloc((nt + 2) * 8));
       HIP_TRY(launch_wr_count_defined(w.nulls, w.nslots, d_tiles, s));
       HIP_TRY(launch_exclusive_scan(d_tiles, nt, d_tiles.p + nt, s));
@@ -166,25 +185,124 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
   std::vector<IndexEntry> index;
   std::unique_ptr<evql_table> t(new evql_table());
   t->ctx = ctx;
-  auto bitpacked_pages = [&](PageKind kind, uint64_t cid, uint64_t nvalues, uint32_t bits,
-                             std::vector<PageRef>* list) {
-    // BitPackedIntPageWriter: zero-width streams write nothing
-    if (bits == 0) return;
-    const uint64_t nblocks = (nvalues + 127) / 128;
-    for (uint64_t blk = 0, pi = 0; blk < nblocks; blk += kBitpackBlocksPerPage, ++pi) {
-      const uint32_t sz = 16 * bits * kBitpackBlocksPerPage + (pi == 0 ? 4 : 0);
-      list->push_back({pos, sz});
-      index.push_back({kind, cid, {pos, sz}});
-      pos += sz;
+  // every page allocation of the sequential writer, then their order
+  std::vector<PageAlloc> allocs;
+  for (size_t i = 0; i < specs.size(); ++i) {
+    const ColumnSpec& c = specs[i];
+    ColumnWork& w = work[i];
+    auto level_pages = [&](uint32_t stream, uint32_t bits) {
+      // BitPackedIntPageWriter (page_writer_bitpacked.cc:43-67): zero-width streams
+      // write nothing; page k is allocated by value 131,072 k
+      if (bits == 0) return;
+      const uint64_t nblocks = (w.nslots + 127) / 128;
+      for (uint64_t blk = 0, pi = 0; blk < nblocks; blk += kBitpackBlocksPerPage, ++pi) {
+        const uint32_t sz = 16 * bits * kBitpackBlocksPerPage + (pi == 0 ? 4 : 0);
+        allocs.push_back({0, blk * 128, uint32_t(i), stream, uint32_t(pi), sz});
+      }
+    };
+    if (c.rlevel_max > 0) level_pages(0, bitpack_width(c.rlevel_max));
+    if (c.dlevel_max > 0) level_pages(1, bitpack_width(c.dlevel_max));
+    // data pages: index of the (defined) value that allocates each
+    std::vector<uint64_t> first_value;
+    std::vector<uint32_t> sizes;
+    switch (c.storage_type) {
+      case ColumnEncoding::UINT64_PLAIN:
+      case ColumnEncoding::FLOAT_IEEE754:
+        for (uint64_t v = 0; v < w.ndef; v += kPlainPageSize / 8) {
+          first_value.push_back(v);
+          sizes.push_back(kPlainPageSize);
+        }
+        break;
+      case ColumnEncoding::UINT32_PLAIN:
+        for (uint64_t v = 0; v < w.ndef; v += kPlainPageSize / 4) {
+          first_value.push_back(v);
+          sizes.push_back(kPlainPageSize);
+        }
+        break;
+      case ColumnEncoding::UINT32_BITPACKED:
+      case ColumnEncoding::BOOLEAN_BITPACKED:
+        if (w.bits) {
+          for (uint64_t v = 0, pi = 0; v < w.ndef; v += 128ull * kBitpackBlocksPerPage, ++pi) {
+            first_value.push_back(v);
+            sizes.push_back(16 * w.bits * kBitpackBlocksPerPage + (pi == 0 ? 4 : 0));
+          }
+        }
+        break;
+      default: {  // LEB128 / strings: the value holding stream byte 524,288 k
+        const uint64_t npages = (w.leb_bytes + kPlainPageSize - 1) / kPlainPageSize;
+        if (npages) {
+          std::vector<uint64_t> qs(npages);
+          for (uint64_t k = 0; k < npages; ++k) qs[k] = k * uint64_t(kPlainPageSize);
+          DevBuf<uint64_t> d_q;
+          HIP_TRY(d_q.alloc(npages * 16));
+          HIP_TRY(hipMemcpyAsync(d_q, qs.data(), npages * 8, hipMemcpyHostToDevice, s));
+          HIP_TRY(launch_wr_select_byte(w.dense, w.ndef, w.chunk_offsets,
+                                        c.storage_type == ColumnEncoding::STRING_PLAIN, d_q, npages,
+                                        d_q.p + npages, s));
+          first_value.resize(npages);
+          HIP_TRY(hipMemcpyAsync(first_value.data(), d_q.p + npages, npages * 8,
+                                 hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+          sizes.assign(npages, kPlainPageSize);
+        }
+      }
     }
-  };
-  auto plain_pages = [&](uint64_t cid, uint64_t nbytes, std::vector<PageRef>* list) {
-    for (uint64_t b = 0; b < nbytes; b += kPlainPageSize) {
-      list->push_back({pos, kPlainPageSize});
-      index.push_back({PageKind::DATA, cid, {pos, kPlainPageSize}});
-      pos += kPlainPageSize;
+    // ... and the slot that carries it (NULL / undefined slots carry no value)
+    std::vector<uint64_t> slot_of = first_value;
+    if (c.dlevel_max > 0 && !first_value.empty()) {
+      const uint64_t nq = first_value.size();
+      DevBuf<uint64_t> d_q;
+      HIP_TRY(d_q.alloc(nq * 16));
+      HIP_TRY(hipMemcpyAsync(d_q, first_value.data(), nq * 8, hipMemcpyHostToDevice, s));
+      HIP_TRY(launch_wr_select_zero(w.nulls, w.nslots, w.def_tiles, d_q, nq, d_q.p + nq, s));
+      HIP_TRY(hipMemcpyAsync(slot_of.data(), d_q.p + nq, nq * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
     }
-  };
+    for (size_t k = 0; k < first_value.size(); ++k) {
+      allocs.push_back({0, slot_of[k], uint32_t(i), 2, uint32_t(k), sizes[k]});
+    }
+  }
+  if (page_order == EVQL_PAGE_ORDER_ROWS) {
+    // the record that writes each slot: flat columns one slot per row; repeated columns
+    // the number of slots with repetition level 0 up to and including it, minus one
+    for (size_t i = 0; i < specs.size(); ++i) {
+      std::vector<size_t> mine;
+      for (size_t a = 0; a < allocs.size(); ++a) {
+        if (allocs[a].column == i) mine.push_back(a);
+      }
+      if (specs[i].rlevel_max == 0 || mine.empty()) {
+        for (size_t a : mine) allocs[a].record = allocs[a].slot;
+        continue;
+      }
+      const ColumnWork& w = work[i];
+      const uint64_t nt = (w.nslots + kDecodeTile - 1) / kDecodeTile;
+      DevBuf<uint64_t> d_tiles, d_q;
+      HIP_TRY(d_tiles.alloc((nt + 2) * 8));
+      HIP_TRY(launch_wr_count_defined(in[i].rlevels, w.nslots, d_tiles, s));  // counts zeros
+      HIP_TRY(launch_exclusive_scan(d_tiles, nt, d_tiles.p + nt, s));
+      std::vector<uint64_t> qs(mine.size()), rk(mine.size());
+      for (size_t k = 0; k < mine.size(); ++k) qs[k] = allocs[mine[k]].slot;
+      HIP_TRY(d_q.alloc(qs.size() * 16));
+      HIP_TRY(hipMemcpyAsync(d_q, qs.data(), qs.size() * 8, hipMemcpyHostToDevice, s));
+      HIP_TRY(launch_wr_rank_zero(in[i].rlevels, w.nslots, d_tiles, d_q, qs.size(),
+                                  d_q.p + qs.size(), s));
+      HIP_TRY(hipMemcpyAsync(rk.data(), d_q.p + qs.size(), qs.size() * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      for (size_t k = 0; k < mine.size(); ++k) allocs[mine[k]].record = rk[k] ? rk[k] - 1 : 0;
+    }
+    std::stable_sort(allocs.begin(), allocs.end(), [](const PageAlloc& a, const PageAlloc& b) {
+      if (a.record != b.record) return a.record < b.record;
+      if (a.column != b.column) return a.column < b.column;
+      if (a.slot != b.slot) return a.slot < b.slot;
+      return a.stream < b.stream;
+    });
+  } else {
+    std::stable_sort(allocs.begin(), allocs.end(), [](const PageAlloc& a, const PageAlloc& b) {
+      if (a.column != b.column) return a.column < b.column;
+      if (a.slot != b.slot) return a.slot < b.slot;
+      return a.stream < b.stream;
+    });
+  }
   for (size_t i = 0; i < specs.size(); ++i) {
     const ColumnSpec& c = specs[i];
     const ColumnWork& w = work[i];
@@ -196,39 +314,39 @@ Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& s
     cl.rlevel_max = c.rlevel_max;
     cl.dlevel_max = c.dlevel_max;
     uint64_t payload = 0;
-    // (ColumnWriter::write* appends the repetition level, then the definition level,
-    // then the value: ColumnWriter.cc:59-89)
-    if (c.rlevel_max > 0) {
-      const uint32_t rbits = bitpack_width(c.rlevel_max);
-      bitpacked_pages(PageKind::RLEVEL, c.column_id, w.nslots, rbits, &cl.rlevel_pages);
-      if (w.nslots) payload += 4 + 16ull * rbits * ((w.nslots + 127) / 128);
+    if (c.rlevel_max > 0 && w.nslots) {
+      payload += 4 + 16ull * bitpack_width(c.rlevel_max) * ((w.nslots + 127) / 128);
     }
-    if (c.dlevel_max > 0) {
-      const uint32_t dbits = bitpack_width(c.dlevel_max);
-      bitpacked_pages(PageKind::DLEVEL, c.column_id, w.nslots, dbits, &cl.dlevel_pages);
-      if (w.nslots) payload += 4 + 16ull * dbits * ((w.nslots + 127) / 128);
+    if (c.dlevel_max > 0 && w.nslots) {
+      payload += 4 + 16ull * bitpack_width(c.dlevel_max) * ((w.nslots + 127) / 128);
     }
     switch (c.storage_type) {
       case ColumnEncoding::UINT64_PLAIN:
       case ColumnEncoding::FLOAT_IEEE754:
-        plain_pages(c.column_id, w.ndef * 8, &cl.data_pages);
         payload += w.ndef * 8;
         break;
       case ColumnEncoding::UINT32_PLAIN:
-        plain_pages(c.column_id, w.ndef * 4, &cl.data_pages);
         payload += w.ndef * 4;
         break;
       case ColumnEncoding::UINT32_BITPACKED:
       case ColumnEncoding::BOOLEAN_BITPACKED:
-        bitpacked_pages(PageKind::DATA, c.column_id, w.ndef, w.bits, &cl.data_pages);
         if (w.ndef && w.bits) payload += 4 + 16ull * w.bits * ((w.ndef + 127) / 128);
         break;
       default:
-        plain_pages(c.column_id, w.leb_bytes, &cl.data_pages);
         payload += w.leb_bytes;
     }
     t->layout.columns.push_back(cl);
     t->payload_bytes.push_back(payload);
+  }
+  for (const PageAlloc& a : allocs) {
+    ColumnLayout& cl = t->layout.columns[a.column];
+    std::vector<PageRef>& list =
+        a.stream == 0 ? cl.rlevel_pages : (a.stream == 1 ? cl.dlevel_pages : cl.data_pages);
+    // (within one stream the allocations are already in page order)
+    list.push_back({pos, a.size});
+    index.push_back({a.stream == 0 ? PageKind::RLEVEL : (a.stream == 1 ? PageKind::DLEVEL : PageKind::DATA),
+                     specs[a.column].column_id, {pos, a.size}});
+    pos += a.size;
   }
   const uint64_t index_offset = pos;
   std::vector<uint8_t> idx;

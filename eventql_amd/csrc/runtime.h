@@ -320,5 +320,5 @@ struct DeviceColumnIn {
 };
 Status table_from_device_columns(evql_ctx* ctx, const std::vector<ColumnSpec>& specs,
                                  const std::vector<DeviceColumnIn>& in, uint64_t num_rows,
-                                 evql_table** out);
+                                 int page_order, evql_table** out);
 }  // namespace evql

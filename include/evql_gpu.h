@@ -346,14 +346,25 @@ typedef struct {
  * BOOLEAN_BITPACKED, UINT64_LEB128 or STRING_PLAIN (LenencStringPageWriter,
  * io/cstable/columns/page_writer_lenencstring.cc:37-69).  Repeated / nested columns
  * are given as level arrays + values per slot (ColumnWriter::write*(r, d, v),
- * io/cstable/ColumnWriter.cc:59-89).  Pages are placed
- * column after column (an optional column's definition levels before its data);
- * for required columns the file is byte-identical to the one evql_writer_*
- * produces from the same values.
+ * io/cstable/ColumnWriter.cc:59-89).  Pages are placed in the order
+ * PageManager::allocPage (io/cstable/page_manager.cc:50-74) would have handed them out
+ * to a sequential writer, so the file is byte-identical to the one that writer (or
+ * evql_writer_*) produces from the same values:
+ *   EVQL_PAGE_ORDER_COLUMNS  the writer that appends one whole column after the other
+ *   EVQL_PAGE_ORDER_ROWS     the writer that appends row by row / record by record,
+ *                            every column per row in column order (RecordShredder,
+ *                            io/cstable/RecordShredder.cc:113-176; ties inside one
+ *                            record of a nested schema follow the column order)
+ * evql_table_from_device_columns = EVQL_PAGE_ORDER_COLUMNS.
  */
+typedef enum { EVQL_PAGE_ORDER_COLUMNS = 0, EVQL_PAGE_ORDER_ROWS = 1 } evql_page_order_t;
 int evql_table_from_device_columns(evql_ctx_t* ctx, const evql_column_spec_t* cols,
                                    int ncols, const evql_device_column_t* data,
                                    uint64_t num_rows, evql_table_t** out);
+int evql_table_from_device_columns_ordered(evql_ctx_t* ctx, const evql_column_spec_t* cols,
+                                           int ncols, const evql_device_column_t* data,
+                                           uint64_t num_rows, int page_order,
+                                           evql_table_t** out);
 
 /* ------------------------------------------------------------------------ */
 /* the operator: GroupByExpression over FastCSTableScan / CSTableScan         */

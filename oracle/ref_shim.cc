@@ -189,6 +189,49 @@ int ref_writer_put_string(
   REF_CATCH(-1)
 }
 
+/* Record by record, every column per record in the order given -- the call order of a
+ * row-wise writer (cstable_writer.cc addRow loops; RecordShredder.cc:113-176 writes the
+ * fields of one record before the next).  Column c has nslots[c] (r, d, value) triples;
+ * a record takes the slots up to the next r == 0 (rl[c] == NULL: one slot per record).
+ * kinds: 0 uint, 1 float.  dl[c] == NULL: present[c] (or all present) decides. */
+int ref_writer_put_records(
+    void* h, int ncols, const char* const* cols, const int* kinds,
+    const uint64_t* nslots, const uint64_t* const* rl, const uint64_t* const* dl,
+    const uint8_t* const* present, const uint64_t* const* values, uint64_t nrecords) {
+  REF_TRY
+  auto w = ((RefWriter*) h)->w;
+  std::vector<RefPtr<ColumnWriter>> cw;
+  std::vector<uint64_t> cur(ncols, 0);
+  for (int c = 0; c < ncols; ++c) cw.push_back(w->getColumnWriter(cols[c]));
+  for (uint64_t rec = 0; rec < nrecords; ++rec) {
+    for (int c = 0; c < ncols; ++c) {
+      auto dmax = cw[c]->maxDefinitionLevel();
+      bool first = true;
+      while (cur[c] < nslots[c]) {
+        uint64_t i = cur[c];
+        uint64_t r = rl[c] ? rl[c][i] : 0;
+        if (!first && r == 0) break;
+        if (!rl[c] && !first) break;
+        first = false;
+        uint64_t d = dl[c] ? dl[c][i] : dmax;
+        if (!dl[c] && present[c] && !present[c][i]) d = dmax > 0 ? dmax - 1 : 0;
+        if (d != dmax) {
+          cw[c]->writeNull(r, d);
+        } else if (kinds[c] == 1) {
+          double f;
+          memcpy(&f, &values[c][i], 8);
+          cw[c]->writeFloat(r, d, f);
+        } else {
+          cw[c]->writeUnsignedInt(r, d, values[c][i]);
+        }
+        ++cur[c];
+      }
+    }
+  }
+  return 0;
+  REF_CATCH(-1)
+}
+
 int ref_writer_commit(void* h, uint64_t nrows) {
   REF_TRY
   auto w = ((RefWriter*) h)->w;

@@ -266,6 +266,49 @@ def ref_write_table(path, schema_nodes, columns, num_rows):
         L.ref_writer_free(w)
 
 
+def ref_write_table_by_records(path, schema_nodes, columns, num_records):
+    """REFERENCE writer, record by record: every column per record in the order given
+    (the call order of a row-wise writer, ref_shim.cc ref_writer_put_records).
+    columns: list of (flat_name, 'uint'|'float', value words (u64 / f64 bits),
+             rlvl|None, dlvl|None, present|None), one entry per slot"""
+    L = ref()
+    L.ref_writer_put_records.argtypes = [
+        C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), _u64p,
+        C.POINTER(_u64p), C.POINTER(_u64p), C.POINTER(_u8p), C.POINTER(_u64p), C.c_uint64]
+    n = len(schema_nodes)
+    names = (C.c_char_p * n)(*[s["name"].encode() for s in schema_nodes])
+    arr = lambda k: (C.c_int * n)(*[int(s[k]) for s in schema_nodes])
+    w = L.ref_writer_create(path.encode(), n, names, arr("type"), arr("encoding"),
+                            arr("repeated"), arr("optional"), arr("parent"))
+    if not w:
+        raise IOError(L.ref_last_error().decode())
+    try:
+        nc = len(columns)
+        keep = []
+
+        def ptr(a, dt, pt):
+            if a is None:
+                return pt()
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return _np_ptr(a, pt)
+        cnames = (C.c_char_p * nc)(*[c[0].encode() for c in columns])
+        kinds = (C.c_int * nc)(*[1 if c[1] == "float" else 0 for c in columns])
+        nslots = np.array([len(c[2]) for c in columns], np.uint64)
+        vals = (_u64p * nc)(*[ptr(np.asarray(c[2]).view(np.uint64), np.uint64, _u64p) for c in columns])
+        rls = (_u64p * nc)(*[ptr(c[3], np.uint64, _u64p) for c in columns])
+        dls = (_u64p * nc)(*[ptr(c[4], np.uint64, _u64p) for c in columns])
+        prs = (_u8p * nc)(*[ptr(c[5], np.uint8, _u8p) for c in columns])
+        rc = L.ref_writer_put_records(w, nc, cnames, kinds, _np_ptr(nslots, _u64p), rls, dls, prs,
+                                      vals, num_records)
+        if rc != 0:
+            raise IOError(L.ref_last_error().decode())
+        if L.ref_writer_commit(w, num_records) != 0:
+            raise IOError(L.ref_last_error().decode())
+    finally:
+        L.ref_writer_free(w)
+
+
 # ---------------------------------------------------------------------------
 # oracle query runner
 # ---------------------------------------------------------------------------

@@ -1,7 +1,10 @@
 """Device-side cstable writer (evql_table_from_device_columns) against the host
-writer (evql_writer_*, itself validated against the reference's reader): the file
-bytes for required columns, the decoded (d, value) streams through the oracle's
-reader for optional ones, and query results over the written table."""
+writer (evql_writer_*, itself validated against the reference's reader and writer) and
+against the reference's own CSTableWriter (oracle/_ref): the file bytes -- in both page
+placement orders a sequential writer produces --, the decoded (d, value) streams through
+the oracle's and the reference's reader, and query results over the written table."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -101,9 +104,8 @@ def test_optional_columns_round_trip(ctx, n, tmp_path):
     t = device_table(ctx, specs, c, n)
     dev = t.download_image()
     host = host_image(specs, c, n)
-    if n <= 5000:
-        # every stream fits one page: same page order as the host writer
-        assert dev == host
+    # page for page in the order a column-after-column writer allocates them
+    assert dev == host
     path = str(tmp_path / "dev.cst")
     with open(path, "wb") as f:
         f.write(dev)
@@ -202,10 +204,7 @@ def test_string_columns_are_byte_identical_to_the_host_writer(ctx, n):
     w.commit(n)
     host = w.image()
     w.close()
-    if n <= 2049:
-        assert dev == host  # one page per stream: same placement
-    else:
-        assert len(dev) == len(host)
+    assert dev == host
     # the table written on the device reads like the host-written one, strings included
     if n:
         S = dict(s=K.T_STRING, os=K.T_STRING, x=K.T_UINT64)
@@ -269,10 +268,7 @@ def test_repeated_columns(ctx, nrec):
                 "items.tag": p(t_w)}, None, nrec, heaps={"items.tag": t_h.data_ptr()},
         levels={"items.position": lv, "items.price": lv, "items.tag": lv})
     devimg = t.download_image()
-    if total <= 60_000:
-        assert devimg == host  # one page per stream: same placement
-    else:
-        assert len(devimg) == len(host)
+    assert devimg == host
     if nrec:
         S = {"id": K.T_UINT64, "items.position": K.T_UINT64, "items.price": K.T_UINT64,
              "items.tag": K.T_STRING}
@@ -288,3 +284,137 @@ def test_repeated_columns(ctx, nrec):
             exp2 = O.oracle_run(devimg, plan)
             T.compare_results(exp2.rows(), exp.rows(), exp.types, key_cols=1)
     t.close()
+
+
+def _ref_schema(specs):
+    """flat / one-level nested specs as the reference TableSchema node list"""
+    nodes, parents = [], {}
+    for sp in specs:
+        parts = sp["name"].split(".")
+        parent = -1
+        if len(parts) == 2:
+            if parts[0] not in parents:
+                parents[parts[0]] = len(nodes)
+                nodes.append(dict(name=parts[0], type=K.COL_SUBRECORD, encoding=0, repeated=1,
+                                  optional=0, parent=-1))
+            parent = parents[parts[0]]
+        nodes.append(dict(name=parts[-1], type=sp["logical_type"], encoding=sp["storage_type"],
+                          repeated=0, optional=1 if sp.get("dlevel_max", 0) and parent < 0 else
+                          (1 if sp.get("optional") else 0), parent=parent))
+    return nodes
+
+
+def _in_reference_header_order(specs, tmp_path):
+    """the reference lists the columns of the file header in the order of its schema
+    map, not of declaration: learn that order (and the column ids) from an empty file
+    and use it as the declaration AND write order of both writers"""
+    path = str(tmp_path / "order.cst")
+    if os.path.exists(path):
+        os.unlink(path)
+    O.ref_write_table_by_records(path, _ref_schema(specs), [], 0)
+    r = O.TableReader(path, "ref")
+    hdr = r.columns()
+    r.close()
+    by_name = {s["name"]: s for s in specs}
+    return [dict(by_name[h["name"]], column_id=h["column_id"]) for h in hdr]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (the reference's cstable library) not built")
+@pytest.mark.parametrize("n", [1, 129, 131_073, 700_001])
+def test_row_order_is_byte_identical_to_the_reference_writer(ctx, n, tmp_path):
+    """EVQL_PAGE_ORDER_ROWS: the file the REFERENCE's CSTableWriter produces when a table
+    is written row by row, every column per row (11 PLAIN64 pages, 6 bit-packed level
+    pages and 5-7 LEB128 pages per stream at 700,001 rows, allocated interleaved)"""
+    c = make_columns(n, 300 + n)
+    bitpacked = {K.ENC_UINT32_BITPACKED, K.ENC_BOOLEAN_BITPACKED}
+    # (TableSchema carries no bit-pack maximum: the reference writer uses the defaults)
+    specs = [s for s in OPTIONAL + REQUIRED
+             if s["storage_type"] not in bitpacked or "bitpack_max_value" not in s]
+    declared = specs
+    specs = _in_reference_header_order(declared, tmp_path)
+    t = _device_table(ctx, specs, c, n, K.PAGE_ORDER_ROWS)
+    dev = t.download_image()
+    t.close()
+    cols = []
+    for s in specs:
+        name = s["name"]
+        pres = (1 - c[name + "_null"]).astype(np.uint8) if s.get("dlevel_max", 0) else None
+        cols.append((name, "float" if s["logical_type"] == F else "uint", c[name], None, None, pres))
+    path = str(tmp_path / "ref.cst")
+    O.ref_write_table_by_records(path, _ref_schema(declared), cols, n)
+    ref = open(path, "rb").read()
+    assert len(dev) == len(ref)
+    assert dev == ref
+    # the column-after-column order is a different file
+    if n > 131_072:
+        t2 = _device_table(ctx, specs, c, n, K.PAGE_ORDER_COLUMNS)
+        other = t2.download_image()
+        t2.close()
+        assert other != ref  # (index offsets are varuints: even the length may differ)
+
+
+def _device_table(ctx, specs, c, n, order):
+    keep, vals, nulls = [], {}, {}
+    for s in specs:
+        name = s["name"]
+        tv = torch.from_numpy(c[name].view(np.int64).copy()).cuda()
+        keep.append(tv)
+        vals[name] = tv.data_ptr()
+        if s.get("dlevel_max", 0):
+            tn = torch.from_numpy(c[name + "_null"].copy()).cuda()
+            keep.append(tn)
+            nulls[name] = tn.data_ptr()
+    torch.cuda.synchronize()
+    t = ctx.table_from_device_columns(specs, vals, nulls, n, page_order=order)
+    del keep
+    return t
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (the reference's cstable library) not built")
+@pytest.mark.parametrize("nrec", [300, 200_000])
+def test_row_order_of_repeated_columns(ctx, nrec, tmp_path):
+    """record by record with a REPEATED RECORD: a level page of `items.*` is allocated
+    by the record that holds slot 131,072 k, a data page by the record of its first value"""
+    rng = np.random.default_rng(70 + nrec)
+    cnt = np.minimum(rng.geometric(0.3, nrec) - 1, 9)
+    slots = np.maximum(cnt, 1)
+    total = int(slots.sum())
+    starts = np.concatenate([[0], np.cumsum(slots)[:-1]]).astype(np.int64)
+    rl = np.ones(total, np.uint8)
+    rl[starts] = 0
+    rec_of_slot = np.repeat(np.arange(nrec), slots)
+    dl = np.where(cnt[rec_of_slot] > 0, 2, 1).astype(np.uint8)  # empty list: d = 1
+    pos = (np.arange(total) - starts[rec_of_slot] + 1).astype(np.uint64)
+    price = rng.integers(1, 1 << 50, total).astype(np.uint64)
+    ids = np.arange(nrec, dtype=np.uint64) * np.uint64(7)
+    score = rng.normal(0, 10, nrec)
+    specs = [dict(name="id", logical_type=U, storage_type=K.ENC_UINT64_PLAIN),
+             dict(name="items.position", logical_type=U, storage_type=K.ENC_UINT32_PLAIN,
+                  rlevel_max=1, dlevel_max=2, optional=1),
+             dict(name="items.price", logical_type=U, storage_type=K.ENC_UINT64_LEB128,
+                  rlevel_max=1, dlevel_max=2, optional=1),
+             dict(name="score", logical_type=F, storage_type=K.ENC_FLOAT_IEEE754)]
+    declared = specs
+    specs = _in_reference_header_order(declared, tmp_path)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype.itemsize == 8 else a.dtype).copy()).cuda()
+    t_id, t_pos, t_price, t_sc = dev(ids), dev(pos), dev(price), dev(score)
+    t_rl, t_dl = torch.from_numpy(rl.copy()).cuda(), torch.from_numpy(dl.copy()).cuda()
+    torch.cuda.synchronize()
+    lv = (t_rl.data_ptr(), t_dl.data_ptr(), total)
+    t = ctx.table_from_device_columns(
+        specs, {"id": t_id.data_ptr(), "items.position": t_pos.data_ptr(),
+                "items.price": t_price.data_ptr(), "score": t_sc.data_ptr()}, None, nrec,
+        levels={"items.position": lv, "items.price": lv}, page_order=K.PAGE_ORDER_ROWS)
+    devimg = t.download_image()
+    t.close()
+    r64, d64 = rl.astype(np.uint64), dl.astype(np.uint64)
+    by_name = {"id": ("id", "uint", ids, None, None, None),
+               "items.position": ("items.position", "uint", pos, r64, d64, None),
+               "items.price": ("items.price", "uint", price, r64, d64, None),
+               "score": ("score", "float", score, None, None, None)}
+    cols = [by_name[sp["name"]] for sp in specs]
+    path = str(tmp_path / "ref.cst")
+    O.ref_write_table_by_records(path, _ref_schema(declared), cols, nrec)
+    ref = open(path, "rb").read()
+    assert len(devimg) == len(ref)
+    assert devimg == ref
