@@ -168,6 +168,133 @@ __global__ void __launch_bounds__(kBlock) k_owner_scatter(const u64* records, u6
   }
 }
 
+// ---- count_distinct across GPUs: the (group, value, flags) triples of a pair set
+// (evql_device.h evql_pairset_insert) travel in their stored form to the rank that owns the
+// group and are re-inserted there; the triple that is new to the merged set adds 1 to
+// its group's state word (aggregate.cc:119-137 merges the std::sets).
+__global__ void __launch_bounds__(kBlock) k_pairset_export(const u64* tab, u64 cap, u64* out,
+                                                           u64 max_triples, u64* counter) {
+  __shared__ u64 base_s;
+  const u64 rounds = (cap + (u64) gridDim.x * blockDim.x - 1) / ((u64) gridDim.x * blockDim.x);
+  for (u64 it = 0; it < rounds; ++it) {
+    const u64 s = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    // (a triple is complete once its last word is claimed)
+    const bool occ = s < cap && tab[2 * cap + s] != EVQL_EMPTY;
+    u32 total;
+    const u32 ex = block_excl_scan(occ ? 1u : 0u, &total);
+    if (threadIdx.x == 0) base_s = total ? atomicAdd((unsigned long long*) counter, (unsigned long long) total) : 0;
+    __syncthreads();
+    const u64 idx = base_s + ex;
+    __syncthreads();
+    if (!occ || idx >= max_triples) continue;
+    out[idx * 3] = tab[s];
+    out[idx * 3 + 1] = tab[cap + s];
+    out[idx * 3 + 2] = tab[2 * cap + s];
+  }
+}
+
+// owner of a triple = owner of its group's record (record_owner)
+__device__ __forceinline__ u32 triple_owner(const u64* t, u32 nranks, u32 exact_key) {
+  if (exact_key && (t[2] & 3u)) return 0u;  // NULL key / the key 2^64-1: kind != 0
+  return (u32) (evql_mix64(t[0] ^ 0x2545f4914f6cdd1dull) % nranks);
+}
+
+__global__ void __launch_bounds__(kBlock) k_triple_owner_hist(const u64* triples, u64 n, u32 nranks,
+                                                              u32 exact_key, u64* counts) {
+  __shared__ u32 h[kMaxExchangeRanks];
+  if (threadIdx.x < kMaxExchangeRanks) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    atomicAdd(&h[triple_owner(triples + i * 3, nranks, exact_key)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nranks && h[threadIdx.x]) {
+    atomicAdd((unsigned long long*) &counts[threadIdx.x], (unsigned long long) h[threadIdx.x]);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_triple_owner_scatter(const u64* triples, u64 n,
+                                                                 u32 nranks, u32 exact_key,
+                                                                 const u64* starts, u64* cursors,
+                                                                 u64* out) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* t = triples + i * 3;
+    const u32 o = triple_owner(t, nranks, exact_key);
+    const u64 pos = starts[o] + atomicAdd((unsigned long long*) &cursors[o], 1ull);
+    out[pos * 3] = t[0];
+    out[pos * 3 + 1] = t[1];
+    out[pos * 3 + 2] = t[2];
+  }
+}
+
+// slot of an EXISTING group (every group with a triple had its record merged before)
+__device__ __forceinline__ i64 gtab_lookup(const u64* tab, u32 W, u64 cap, u64 ident, u64 ident2,
+                                           bool two) {
+  const u64 mask = cap - 1;
+  u64 s = evql_mix64(ident) & mask;
+  const u64 maxp = cap < EVQL_GTAB_MAX_PROBE ? cap : EVQL_GTAB_MAX_PROBE;
+  for (u64 probe = 0; probe < maxp; ++probe, s = (s + 1) & mask) {
+    const u64 cur = tab[s * W];
+    if (cur == EVQL_EMPTY) return -1;
+    if (cur == ident && (!two || tab[s * W + 1] == ident2)) return (i64) s;
+  }
+  return -1;
+}
+
+__global__ void __launch_bounds__(kBlock) k_pairset_merge(PairsetMergeArgs a, const u64* triples,
+                                                          u64 n) {
+  const u64 mask = a.set_cap - 1;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 ident = triples[i * 3], value = triples[i * 3 + 1], flags = triples[i * 3 + 2];
+    // insert the stored form as it is (same claim protocol as evql_pairset_insert)
+    u64 s = evql_mix64(evql_hash_combine(evql_hash_combine(ident, value), flags)) & mask;
+    const u64 maxp = a.set_cap < 256 ? a.set_cap : 256;
+    int fresh = -1;
+    for (u64 probe = 0; probe < maxp && fresh < 0; ++probe, s = (s + 1) & mask) {
+      u64* set = (u64*) a.set;
+      u64 c0 = __hip_atomic_load(set + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c0 == EVQL_EMPTY) c0 = atomicCAS(set + s, EVQL_EMPTY, ident);
+      if (c0 != EVQL_EMPTY && c0 != ident) continue;
+      u64 c1 = __hip_atomic_load(set + a.set_cap + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c1 == EVQL_EMPTY) c1 = atomicCAS(set + a.set_cap + s, EVQL_EMPTY, value);
+      if (c1 != EVQL_EMPTY && c1 != value) continue;
+      u64 c2 = __hip_atomic_load(set + 2 * a.set_cap + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c2 == EVQL_EMPTY) {
+        c2 = atomicCAS(set + 2 * a.set_cap + s, EVQL_EMPTY, flags);
+        if (c2 == EVQL_EMPTY) fresh = 1;
+      }
+      if (fresh < 0 && c2 == flags) fresh = 0;
+    }
+    if (fresh < 0) {
+      atomicOr(&a.status[0], EVQL_ST_PAIRSET_FULL);
+      continue;
+    }
+    if (!fresh) continue;
+    // the group this pair belongs to
+    i64 gs;
+    if (a.key_mode == 1) {  // exact key: flags = NULL-key bit | escape bits
+      if (flags & 1u) gs = (i64) a.gcap + 1;
+      else if (flags & 2u) gs = (i64) a.gcap;
+      else gs = gtab_lookup((const u64*) a.words, a.nwords, a.gcap, ident, 0, false);
+    } else if (a.key_mode == 2) {  // hashed key: flags = second identity word, scrambled
+      gs = gtab_lookup((const u64*) a.words, a.nwords, a.gcap, ident, flags, true);  // when value was 2^64-1
+      if (gs < 0 && value == EVQL_EMPTY - 1) {
+        gs = gtab_lookup((const u64*) a.words, a.nwords, a.gcap, ident, flags ^ 0xc2b2ae3d27d4eb4full, true);
+      }
+    } else {
+      gs = gtab_lookup((const u64*) a.words, a.nwords, a.gcap, ident, 0, false);
+    }
+    if (gs < 0) {
+      atomicOr(&a.status[0], EVQL_ST_TABLE_FULL);  // (cannot happen: the record came first)
+      continue;
+    }
+    atomicAdd((unsigned long long*) &a.words[(u64) gs * a.nwords + a.word], 1ull);
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) k_resolve_records(ResolveArgs a) {
   const u32 ow = a.in_words + a.ncols + 1;
   for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
@@ -1449,6 +1576,40 @@ hipError_t launch_owner_scatter(const uint64_t* records, uint64_t n, uint32_t rw
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_owner_scatter, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) records,
                      (u64) n, rw, nranks, (const u64*) starts, (u64*) cursors, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_pairset_export(const uint64_t* tab, uint64_t cap, uint64_t* out,
+                                 uint64_t max_triples, uint64_t* counter, hipStream_t s) {
+  if (cap == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pairset_export, dim3(grid_for(cap, kBlock, 2048)), dim3(kBlock), 0, s,
+                     (const u64*) tab, (u64) cap, (u64*) out, (u64) max_triples, (u64*) counter);
+  return hipGetLastError();
+}
+
+hipError_t launch_triple_owner_hist(const uint64_t* triples, uint64_t n, uint32_t nranks,
+                                    bool exact_key, uint64_t* counts, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_triple_owner_hist, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), 0, s,
+                     (const u64*) triples, (u64) n, nranks, exact_key ? 1u : 0u, (u64*) counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_triple_owner_scatter(const uint64_t* triples, uint64_t n, uint32_t nranks,
+                                       bool exact_key, const uint64_t* starts, uint64_t* cursors,
+                                       uint64_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_triple_owner_scatter, dim3(grid_for(n)), dim3(kBlock), 0, s,
+                     (const u64*) triples, (u64) n, nranks, exact_key ? 1u : 0u, (const u64*) starts,
+                     (u64*) cursors, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_pairset_merge(const PairsetMergeArgs& a, const uint64_t* triples, uint64_t n,
+                                hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pairset_merge, dim3(grid_for(n)), dim3(kBlock), 0, s, a, (const u64*) triples,
+                     (u64) n);
   return hipGetLastError();
 }
 

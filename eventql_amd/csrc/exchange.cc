@@ -70,7 +70,7 @@ struct evql_exchange {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Slot ws[12];
+  Slot ws[16];
   hipError_t get(int slot, size_t bytes, void** out) {
     Slot& sl = ws[slot];
     if (bytes > sl.cap) {
@@ -183,6 +183,88 @@ double ms_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+static const uint32_t kMergeSkip = 254;  // (rt_atomic knows no such op: the word is left alone)
+
+// count_distinct (aggregate.cc:77-137: a std::set per group, merged by insertion): the
+// stored triples of pair set `which` go to the ranks that own their groups (all ranks
+// for GATHER_ALL) and are inserted into a fresh set there; every triple that is new to
+// it adds 1 to state word `word` of its group in the merged table.
+static Status exchange_pairset(evql_query* q, evql_exchange* x, bool by_owner, int which,
+                               uint32_t word, uint64_t mcap, uint32_t mw) {
+  hipStream_t s = q->ctx->stream;
+  const int N = x->nranks;
+  const bool exact = q->kp.key_mode == KEY_EXACT;
+  uint64_t np = 0;
+  uint64_t* d_cnt = q->d_counters + 6;
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+  if (q->d_pairset[which]) {
+    HIP_TRY(launch_pairset_export(q->d_pairset[which], q->pairset_cap, nullptr, 0, d_cnt, s));
+  }
+  HIP_TRY(hipMemcpyAsync(&np, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  WsBuf<uint64_t> d_tr(x, 11), d_send(x, 12), d_aux(x, 4), d_recv(x, 13), d_set(x, 14);
+  HIP_TRY(d_tr.alloc(std::max<uint64_t>(np, 1) * 24));
+  if (np) {
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+    HIP_TRY(launch_pairset_export(q->d_pairset[which], q->pairset_cap, d_tr, np, d_cnt, s));
+  }
+  std::vector<uint64_t> send_counts(N, np), starts(N + 1, 0);
+  const uint64_t* d_out = d_tr;
+  if (by_owner) {
+    HIP_TRY(d_send.alloc(std::max<uint64_t>(np, 1) * 24));
+    HIP_TRY(d_aux.alloc((3 * kMaxExchangeRanks + 4) * 8));
+    uint64_t* d_counts = d_aux.p;
+    uint64_t* d_starts = d_aux.p + kMaxExchangeRanks;
+    uint64_t* d_cursors = d_aux.p + 2 * kMaxExchangeRanks + 2;
+    HIP_TRY(hipMemsetAsync(d_aux, 0, (3 * kMaxExchangeRanks + 4) * 8, s));
+    HIP_TRY(launch_triple_owner_hist(d_tr, np, uint32_t(N), exact, d_counts, s));
+    HIP_TRY(hipMemcpyAsync(send_counts.data(), d_counts, N * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int r = 0; r < N; ++r) starts[r + 1] = starts[r] + send_counts[r];
+    HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), (N + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_triple_owner_scatter(d_tr, np, uint32_t(N), exact, d_starts, d_cursors, d_send, s));
+    d_out = d_send;
+  } else {
+    // the same triples to everybody (replicated per destination like the records)
+    HIP_TRY(d_send.alloc(std::max<uint64_t>(np * N, 1) * 24));
+    for (int r = 0; r < N; ++r) {
+      HIP_TRY(hipMemcpyAsync(d_send.p + uint64_t(r) * np * 3, d_tr, np * 24, hipMemcpyDeviceToDevice, s));
+    }
+    d_out = d_send;
+  }
+  std::vector<uint64_t> all(uint64_t(N) * N);
+  int rc = x->tr.all_gather_u64(x->tr.user, send_counts.data(), N, all.data());
+  if (rc != EVQL_OK) return Status::error(rc, "exchange: all_gather of the pair counts failed");
+  std::vector<uint64_t> send_words(N), recv_words(N);
+  uint64_t total = 0;
+  for (int r = 0; r < N; ++r) {
+    const uint64_t from_r = all[uint64_t(r) * N + x->rank];
+    send_words[r] = send_counts[r] * 3;
+    recv_words[r] = from_r * 3;
+    total += from_r;
+  }
+  HIP_TRY(d_recv.alloc(std::max<uint64_t>(total, 1) * 24));
+  rc = x->tr.all_to_all_words(x->tr.user, d_out, send_words.data(), d_recv, recv_words.data(), s);
+  if (rc != EVQL_OK) return Status::error(rc, "exchange: transfer of the count_distinct pairs failed");
+  HIP_TRY(hipStreamSynchronize(s));
+  x->stats.bytes_sent += (by_owner ? np : np * uint64_t(N - 1)) * 24;
+  uint64_t set_cap = 1024;
+  while (set_cap < total * 2) set_cap <<= 1;
+  HIP_TRY(d_set.alloc(set_cap * 24));
+  HIP_TRY(hipMemsetAsync(d_set, 0xff, set_cap * 24, s));
+  PairsetMergeArgs pa{};
+  pa.set = d_set;
+  pa.set_cap = set_cap;
+  pa.words = q->d_mtab;
+  pa.gcap = mcap;
+  pa.nwords = mw;
+  pa.word = word;
+  pa.key_mode = uint32_t(q->kp.key_mode);
+  pa.status = q->d_status;
+  HIP_TRY(launch_pairset_merge(pa, d_recv, total, s));
+  return Status();
+}
+
 // -----------------------------------------------------------------------------------------
 // the exchange itself
 // -----------------------------------------------------------------------------------------
@@ -193,7 +275,9 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   const KernelPlan& kp = q->kp;
   const int N = x->nranks;
   if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
-  if (kp.n_distinct) return Status::error(EVQL_ENOTSUP, "count_distinct sets do not travel");
+  if (kp.n_distinct && q->group_mode == EVQL_MODE_PARTIAL) {
+    return Status::error(EVQL_ENOTSUP, "count_distinct in a partial aggregate travels as wire rows");
+  }
   if (N > int(kMaxExchangeRanks)) return Status::error(EVQL_EARG, "too many ranks");
   if (q->merged) return Status::error(EVQL_EARG, "the query was exchanged already");
   const uint32_t W = uint32_t(kp.words_per_slot());
@@ -231,7 +315,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
       rc[c].mode = ca.mode;
       rc[c].bits = ca.bits;
       if (q->nested) {
-        rc[c].mode = ColAccess::SOA;
+        rc[c].mode = ColAccess::SOA;  // (the 8-byte words stay beside a packed copy)
         rc[c].soa = ca.string_hash ? q->nested_strpos[c] : q->nested_flat[c];
       } else if (ca.packed) {
         const MaterializedColumn& m = t->materialized[ca.name];
@@ -461,6 +545,11 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   if (kp.has_ident2()) ma.m.ops[w++] = 255;
   if (kp.need_first_row) ma.m.ops[w++] = 2;
   for (const auto& sw : kp.states) ma.m.ops[w++] = uint32_t(sw.op);
+  // a count_distinct word counts the pairs of the MERGED set: foreign counts are not
+  // added, the pairs are exchanged below and counted again
+  for (const auto& ag : kp.aggs) {
+    if (ag.distinct_index >= 0) ma.m.ops[kp.state_word_base() + ag.first_word] = kMergeSkip;
+  }
   ma.m.status = q->d_status;
   ma.state_words = W;
   ma.first_row_word = resolved ? uint32_t(kp.first_row_word()) : 0xffffffffu;
@@ -479,6 +568,13 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     }
     roff += recv_rec[r];
   }
+  // ---- 7. count_distinct: the pair sets follow their groups --------------------------------------
+  for (const auto& ag : kp.aggs) {
+    if (ag.distinct_index < 0) continue;
+    Status st = exchange_pairset(q, x, by_owner, ag.distinct_index,
+                                 uint32_t(kp.state_word_base() + ag.first_word), cap, mw);
+    if (!st.ok()) return st;
+  }
   uint32_t status[4] = {0};
   HIP_TRY(hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s));
   uint64_t* d_cnt = q->d_counters + 4;
@@ -488,6 +584,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   HIP_TRY(hipMemcpyAsync(&ng, d_cnt, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (status[0] & 2u) return Status::error(EVQL_ENOMEM, "merged group table full");
+  if (status[0] & 8u) return Status::error(EVQL_ENOMEM, "merged count_distinct set full");
   // the received string bytes are what the merged groups' string words point into
   q->m_heap.clear();
   if (resolved && !str_cols.empty() && total_heap_words) {

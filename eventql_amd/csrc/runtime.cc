@@ -236,6 +236,8 @@ evql_table::~evql_table() {
   for (auto& kv : nested_cache) {
     if (kv.second.d_values) hipFree(kv.second.d_values);
     if (kv.second.d_hash) hipFree(kv.second.d_hash);
+    if (kv.second.d_packed) hipFree(kv.second.d_packed);
+    if (kv.second.d_packed_pages) hipFree(kv.second.d_packed_pages);
   }
   for (auto& kv : leaf_cache) {
     if (kv.second.levels) hipFree(kv.second.levels);
@@ -356,6 +358,42 @@ static uint64_t fixed_width_capacity(const ColumnLayout& c) {
     default:
       return ~0ull;
   }
+}
+
+// `n` u64 values as bit-packed pages (libsimdcomp layout, 131,072 values per page) of the
+// narrowest of 8 / 16 / 32 bits that holds their maximum; *bits = 0 when it does not fit
+// 32 bits.  Widths dividing 32 never straddle a word: the decode is one shift and one mask.
+static Status pack_narrow(hipStream_t s, const uint64_t* d_values, uint64_t n, uint8_t** d_packed,
+                          uint64_t** d_packed_pages, uint32_t* bits_out) {
+  *bits_out = 0;
+  if (n == 0) return Status();
+  DevBuf<uint64_t> d_max;
+  HIP_TRY(d_max.alloc(8));
+  HIP_TRY(hipMemsetAsync(d_max, 0, 8, s));
+  HIP_TRY(launch_max_u64(d_values, n, d_max, s));
+  uint64_t maxv = 0;
+  HIP_TRY(hipMemcpyAsync(&maxv, d_max, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (maxv > 0xffffffffull) return Status();
+  const uint32_t bits = maxv <= 0xffu ? 8 : (maxv <= 0xffffu ? 16 : 32);
+  const uint64_t nblocks = (n + 127) / 128;
+  const uint64_t page_bytes = 16ull * bits * kBitpackBlocksPerPage;
+  const uint64_t npages = (nblocks + kBitpackBlocksPerPage - 1) / kBitpackBlocksPerPage;
+  // a tile reads up to 8192 rows beyond the last one: zero slack like the image's
+  const uint64_t bytes = 4 + npages * page_bytes + (1 << 20);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(d_packed), bytes));
+  HIP_TRY(hipMemsetAsync(*d_packed, 0, bytes, s));
+  std::vector<uint64_t> offs;
+  for (uint64_t pi = 0; pi < npages; ++pi) offs.push_back(pi == 0 ? 0 : 4 + pi * page_bytes);
+  offs.push_back(offs.back());  // (one past the end stays in bounds)
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(d_packed_pages), offs.size() * 8));
+  HIP_TRY(hipMemcpyAsync(*d_packed_pages, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
+  const uint32_t hdr = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+  HIP_TRY(hipMemcpyAsync(*d_packed, &hdr, 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_wr_bitpack(*d_packed, *d_packed_pages, d_values, nullptr, n, bits, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *bits_out = bits;
+  return Status();
 }
 
 static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* bits_out) {
@@ -500,31 +538,10 @@ static Status materialize_column(evql_table* t, const ColAccess& ca, uint32_t* b
     // never straddle a word).  Decoding LEB128 inside the fused kernel instead would
     // cost ~10 lane-operations per stream byte (terminator scan + extraction) against
     // the ~12 the chip has per HBM byte at 6.3 TB/s for the whole query.
-    DevBuf<uint64_t> d_max;
-    HIP_TRY(d_max.alloc(8));
-    HIP_TRY(hipMemsetAsync(d_max, 0, 8, s));
-    HIP_TRY(launch_max_u64(m.d_values, n, d_max, s));
-    uint64_t maxv = 0;
-    HIP_TRY(hipMemcpyAsync(&maxv, d_max, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (maxv <= 0xffffffffull) {
-      const uint32_t bits = maxv <= 0xffu ? 8 : (maxv <= 0xffffu ? 16 : 32);
-      const uint64_t nblocks = (n + 127) / 128;
-      const uint64_t page_bytes = 16ull * bits * kBitpackBlocksPerPage;
-      const uint64_t npages = (nblocks + kBitpackBlocksPerPage - 1) / kBitpackBlocksPerPage;
-      // a tile reads up to 8192 rows beyond the last one: zero slack like the image's
-      const uint64_t bytes = 4 + npages * page_bytes + (1 << 20);
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_packed), bytes));
-      HIP_TRY(hipMemsetAsync(m.d_packed, 0, bytes, s));
-      std::vector<uint64_t> offs;
-      for (uint64_t pi = 0; pi < npages; ++pi) offs.push_back(pi == 0 ? 0 : 4 + pi * page_bytes);
-      offs.push_back(offs.back());  // (one past the end stays in bounds)
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.d_packed_pages), offs.size() * 8));
-      HIP_TRY(hipMemcpyAsync(m.d_packed_pages, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, s));
-      const uint32_t hdr = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
-      HIP_TRY(hipMemcpyAsync(m.d_packed, &hdr, 4, hipMemcpyHostToDevice, s));
-      HIP_TRY(launch_wr_bitpack(m.d_packed, m.d_packed_pages, m.d_values, nullptr, n, bits, s));
-      HIP_TRY(hipStreamSynchronize(s));
+    uint32_t bits = 0;
+    Status stp = pack_narrow(s, m.d_values, n, &m.d_packed, &m.d_packed_pages, &bits);
+    if (!stp.ok()) return stp;
+    if (bits) {
       m.packed_bits = bits;
       hipFree(m.d_values);  // the 8-byte words are not needed any more
       m.d_values = nullptr;
@@ -823,6 +840,7 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
   }
   const ColumnLayout& lc = t->layout.columns[kp.cols[leaf].layout_index];
   const int leaf_li = kp.cols[leaf].layout_index;
+  q->nested_leaf = leaf_li;
   {
     // every column already flattened for this leaf by an earlier operator?
     bool all = keep == nullptr || lc.rlevel_max == 0 || t->leaf_cache.count(leaf_li);
@@ -1122,7 +1140,7 @@ static Status column_abs_max(evql_query* q, size_t i, double* out) {
   rc.bits = c.bits;
   uint64_t n = t->layout.num_rows;
   if (q->nested) {
-    rc.mode = ColAccess::SOA;
+    rc.mode = ColAccess::SOA;  // (the 8-byte words stay beside a packed copy)
     rc.soa = q->nested_flat[i];
     n = q->nested_rows;
   } else if (c.packed) {
@@ -1254,6 +1272,33 @@ Status query_prepare(evql_query* q) {
   }
   // resolve bit widths and materialise SoA columns
   bool repacked = false;
+  q->nested_packed.assign(q->kp.cols.size(), evql_query::PackedSource{});
+  if (q->nested && !q->within_record && !q->nested_where_mixed && q->nested_leaf >= 0) {
+    // The fused kernel streams the flattened columns; like required LEB128 columns they
+    // are kept once more as bit-packed pages of 8 / 16 / 32 bits where their maximum
+    // fits (config 5: 1 + 4 bytes per row instead of 8 + 8).  Not for string hashes,
+    // nor when WHERE resets rewrite the columns per query (apply_where_resets).
+    for (size_t i = 0; i < q->kp.cols.size(); ++i) {
+      ColAccess& c = q->kp.cols[i];
+      if (c.string_hash || c.stype == EVQL_T_FLOAT64) continue;
+      auto hit = t->nested_cache.find({c.layout_index, q->nested_leaf});
+      if (hit == t->nested_cache.end()) continue;
+      evql_table::NestedFlat& e = hit->second;
+      if (!e.pack_tried) {
+        e.pack_tried = true;
+        Status stp = pack_narrow(q->ctx->stream, e.d_values, e.nflat, &e.d_packed, &e.d_packed_pages,
+                                 &e.packed_bits);
+        if (!stp.ok()) return stp;
+      }
+      if (!e.packed_bits) continue;
+      c.mode = ColAccess::BITPACKED;
+      c.bits = e.packed_bits;
+      c.packed = true;
+      q->nested_packed[i].base = e.d_packed;
+      q->nested_packed[i].pages = e.d_packed_pages;
+      repacked = true;
+    }
+  }
   for (auto& c : q->kp.cols) {
     if (q->nested) break;
     const ColumnLayout& cl = t->layout.columns[c.layout_index];
@@ -1420,7 +1465,10 @@ static void fill_host_args(evql_query* q, HostArgs* ap) {
       a.col[i].pages = t->d_pages[c.layout_index][0];
       a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
     }
-    if (c.packed) {
+    if (c.packed && q->nested) {
+      a.col[i].pages = q->nested_packed[i].pages;
+      a.col[i].base = q->nested_packed[i].base;
+    } else if (c.packed) {
       const MaterializedColumn& m = t->materialized[c.name];
       a.col[i].pages = m.d_packed_pages;
       a.col[i].base = m.d_packed;
@@ -2028,7 +2076,10 @@ static Status fetch_results(evql_query* q) {
       rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
       rc[c].mode = ca.mode;
       rc[c].bits = ca.bits;
-      if (ca.packed) {
+      if (ca.packed && q->nested) {
+        rc[c].pages = q->nested_packed[c].pages;
+        rc[c].base = q->nested_packed[c].base;
+      } else if (ca.packed) {
         const MaterializedColumn& m = t->materialized[ca.name];
         rc[c].pages = m.d_packed_pages;
         rc[c].base = m.d_packed;

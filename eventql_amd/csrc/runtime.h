@@ -173,6 +173,12 @@ struct evql_table {
     uint64_t* d_values = nullptr;  // per row: value bits; strings: (len << 40 | position)
     uint64_t nflat = 0;
     uint64_t* d_hash = nullptr;    // strings: 64-bit hash of the row's bytes
+    // the values once more as bit-packed pages of 8 / 16 / 32 bits (when their maximum
+    // fits): what the fused kernel streams instead of the 8-byte words
+    uint8_t* d_packed = nullptr;
+    uint64_t* d_packed_pages = nullptr;
+    uint32_t packed_bits = 0;
+    bool pack_tried = false;
   };
   std::map<std::pair<int, int>, NestedFlat> nested_cache;
   // record scans (WITHIN RECORD): the leaf's decoded repetition levels (one byte
@@ -234,6 +240,13 @@ struct evql_query {
   uint64_t nested_rows = 0;
   std::vector<uint64_t*> nested_flat;
   std::vector<uint64_t*> nested_strpos;  // string columns: (len << 40 | position) per row
+  // nested scans over narrow bit-packed copies of the flattened columns (ColAccess::packed)
+  struct PackedSource {
+    const uint8_t* base = nullptr;
+    const uint64_t* pages = nullptr;
+  };
+  std::vector<PackedSource> nested_packed;
+  int nested_leaf = -1;  // layout index of the leaf column of the scan
   std::vector<uint64_t*> nested_owned;
   bool nested_where_mixed = false;  // WHERE over columns of different repetition depth
   // EVQL_SCAN_NESTED_WITHIN_RECORD (CSTableScan.cc:440-487,

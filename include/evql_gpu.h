@@ -601,7 +601,9 @@ typedef enum {
  * in every run of the same partial aggregates.  Plans that read first-row values
  * (string / multi-column keys, non-aggregate select expressions) carry them in the
  * records: the first row of the lowest rank that has the group wins, strings travel
- * as bytes.  next_batch then yields the merged groups.  count_distinct: EVQL_ENOTSUP.
+ * as bytes.  next_batch then yields the merged groups.  count_distinct: the (group,
+ * value) pairs follow their groups and are counted again in the merged set
+ * (aggregate.cc:119-137); EVQL_ENOTSUP only together with EVQL_MODE_PARTIAL.
  */
 int evql_query_exchange(evql_query_t* q, evql_exchange_t* x, int mode);
 

@@ -12,7 +12,7 @@ import pytest
 
 import eventql_amd as E
 from eventql_amd import capi as K
-from eventql_amd.plan import Plan, col, count, sum_, min_, max_, mean
+from eventql_amd.plan import Agg, Plan, col, count, sum_, min_, max_, mean
 import oracle_lib as O
 import tables as T
 
@@ -107,6 +107,13 @@ PLANS = {
     "where": dict(select=[col("k"), count(1), sum_(col("v"))], group_by=[col("k")],
                   where=(col("a") > 30000) & (col("s") >= "key-2")),
     "global": dict(select=[count(1), sum_(col("a")), max_(col("v"))], group_by=[], key_cols=0),
+    # count_distinct: the (group, value) pair sets follow their groups (aggregate.cc:119-137)
+    "distinct-u64-key": dict(select=[col("k"), Agg("count_distinct", col("a") % 97), count(1),
+                                     Agg("count_distinct", col("u"))], group_by=[col("k")]),
+    "distinct-string-key": dict(select=[col("ns"), Agg("count_distinct", col("k")), sum_(col("a"))],
+                                group_by=[col("ns")]),
+    "distinct-global": dict(select=[Agg("count_distinct", col("k")), count(1)], group_by=[],
+                            key_cols=0),
 }
 
 
