@@ -2044,13 +2044,25 @@ __global__ void __launch_bounds__(kBlock) k_wr_str_emit(u8* image, const u64* pa
 }  // namespace
 
 // ---- page placement queries (device_writer.cc: in which order the reference's page
-// writers would have allocated their pages).  Few queries (one per page), one thread each:
-// a binary search over the scanned per-tile counts, then a walk inside one 2048-entry tile.
+// writers would have allocated their pages).  Few queries (one per page), one WAVE each:
+// a binary search over the scanned per-tile counts, then the 2048 entries of one tile
+// split over the 64 lanes (32 each: local count, wave prefix sum, the owning lane walks
+// its 32 entries).
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, u32 lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 t = __shfl_up(v, d, 64);
+    if ((int) lane >= d) v += t;
+  }
+  return v;
+}
+
 // select: position of the q-th (0-based) zero byte of flags[0..n)
 __global__ void __launch_bounds__(kBlock) k_wr_select_zero(const u8* flags, u64 n,
                                                            const u64* tile_offsets, u64 ntiles,
                                                            const u64* queries, u64 nq, u64* out) {
-  const u64 qi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  const u64 qi = ((u64) blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63u;
   if (qi >= nq) return;
   const u64 q = queries[qi];
   u64 lo = 0, hi = ntiles;  // last tile whose offset is <= q
@@ -2058,29 +2070,46 @@ __global__ void __launch_bounds__(kBlock) k_wr_select_zero(const u8* flags, u64 
     const u64 mid = (lo + hi) / 2;
     if (tile_offsets[mid] <= q) lo = mid; else hi = mid;
   }
-  u64 seen = tile_offsets[lo];
-  u64 pos = n;
-  for (u64 i = lo * kDecodeTile; i < n && i < (lo + 1) * kDecodeTile; ++i) {
-    if (flags[i] == 0) {
-      if (seen == q) { pos = i; break; }
-      ++seen;
+  const u64 i0 = lo * kDecodeTile + (u64) lane * 32;
+  u32 cnt = 0;
+  for (u32 j = 0; j < 32; ++j) cnt += (i0 + j < n && flags[i0 + j] == 0) ? 1u : 0u;
+  const u32 incl = wave_incl_scan(cnt, lane);
+  const u64 before = tile_offsets[lo] + incl - cnt;  // zeros before this lane's entries
+  u64 pos = ~0ull;
+  if (q >= before && q < before + cnt) {
+    u64 seen = before;
+    for (u32 j = 0; j < 32; ++j) {
+      if (i0 + j < n && flags[i0 + j] == 0) {
+        if (seen == q) { pos = i0 + j; break; }
+        ++seen;
+      }
     }
   }
-  out[qi] = pos;
+  // exactly one lane (or none: q beyond the last zero) holds the answer
+  const u64 ball = __ballot(pos != ~0ull);
+  if (ball == 0) {
+    if (lane == 0) out[qi] = n;
+  } else if (pos != ~0ull) {
+    out[qi] = pos;
+  }
 }
 
 // rank: number of zero bytes in flags[0..q] (inclusive)
 __global__ void __launch_bounds__(kBlock) k_wr_rank_zero(const u8* flags, u64 n,
                                                          const u64* tile_offsets,
                                                          const u64* queries, u64 nq, u64* out) {
-  const u64 qi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  const u64 qi = ((u64) blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63u;
   if (qi >= nq) return;
   u64 q = queries[qi];
   if (q >= n) q = n - 1;
   const u64 t = q / kDecodeTile;
-  u64 cnt = tile_offsets[t];
-  for (u64 i = t * kDecodeTile; i <= q; ++i) cnt += flags[i] == 0 ? 1 : 0;
-  out[qi] = cnt;
+  const u64 i0 = t * kDecodeTile + (u64) lane * 32;
+  u32 cnt = 0;
+  for (u32 j = 0; j < 32; ++j) cnt += (i0 + j <= q && flags[i0 + j] == 0) ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if (lane == 0) out[qi] = tile_offsets[t] + cnt;
 }
 
 // the value whose encoding holds byte q of a LEB128 / STRING_PLAIN stream
@@ -2088,7 +2117,8 @@ __global__ void __launch_bounds__(kBlock) k_wr_select_byte(const u64* dense, u64
                                                            const u64* chunk_offsets, u64 nchunks,
                                                            u32 is_string, const u64* queries,
                                                            u64 nq, u64* out) {
-  const u64 qi = (u64) blockIdx.x * kBlock + threadIdx.x;
+  const u64 qi = ((u64) blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const u32 lane = threadIdx.x & 63u;
   if (qi >= nq) return;
   const u64 q = queries[qi];
   u64 lo = 0, hi = nchunks;
@@ -2096,21 +2126,42 @@ __global__ void __launch_bounds__(kBlock) k_wr_select_byte(const u64* dense, u64
     const u64 mid = (lo + hi) / 2;
     if (chunk_offsets[mid] <= q) lo = mid; else hi = mid;
   }
-  u64 pos = chunk_offsets[lo];
-  u64 idx = n;
-  for (u64 i = lo * kDecodeTile; i < n && i < (lo + 1) * kDecodeTile; ++i) {
-    const u64 len = is_string ? wr_str_size(dense[i]) : wr_leb_len(dense[i]);
-    if (q < pos + len) { idx = i; break; }
-    pos += len;
+  const u64 i0 = lo * kDecodeTile + (u64) lane * 32;
+  u32 bytes = 0;
+  for (u32 j = 0; j < 32; ++j) {
+    if (i0 + j < n) bytes += is_string ? wr_str_size(dense[i0 + j]) : wr_leb_len(dense[i0 + j]);
   }
-  out[qi] = idx;
+  // (a chunk's bytes may pass 2^32 for long strings: 64-bit prefix)
+  u64 incl = bytes;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 tl = __shfl_up((u32) incl, d, 64), th = __shfl_up((u32) (incl >> 32), d, 64);
+    if ((int) lane >= d) incl += ((u64) th << 32) | tl;
+  }
+  const u64 before = chunk_offsets[lo] + incl - bytes;
+  u64 idx = ~0ull;
+  if (q >= before && q < before + bytes) {
+    u64 pos = before;
+    for (u32 j = 0; j < 32; ++j) {
+      if (i0 + j >= n) break;
+      const u64 len = is_string ? wr_str_size(dense[i0 + j]) : wr_leb_len(dense[i0 + j]);
+      if (q < pos + len) { idx = i0 + j; break; }
+      pos += len;
+    }
+  }
+  const u64 ball = __ballot(idx != ~0ull);
+  if (ball == 0) {
+    if (lane == 0) out[qi] = n;
+  } else if (idx != ~0ull) {
+    out[qi] = idx;
+  }
 }
 
 hipError_t launch_wr_select_zero(const uint8_t* flags, uint64_t n, const uint64_t* tile_offsets,
                                  const uint64_t* queries, uint64_t nq, uint64_t* out, hipStream_t s) {
   const u64 ntiles = (n + kDecodeTile - 1) / kDecodeTile;
   if (nq == 0 || ntiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_wr_select_zero, dim3((unsigned) ((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(k_wr_select_zero, dim3((unsigned) ((nq * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      s, flags, (u64) n, (const u64*) tile_offsets, ntiles, (const u64*) queries,
                      (u64) nq, (u64*) out);
   return hipGetLastError();
@@ -2119,7 +2170,7 @@ hipError_t launch_wr_select_zero(const uint8_t* flags, uint64_t n, const uint64_
 hipError_t launch_wr_rank_zero(const uint8_t* flags, uint64_t n, const uint64_t* tile_offsets,
                                const uint64_t* queries, uint64_t nq, uint64_t* out, hipStream_t s) {
   if (nq == 0 || n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_wr_rank_zero, dim3((unsigned) ((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(k_wr_rank_zero, dim3((unsigned) ((nq * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      s, flags, (u64) n, (const u64*) tile_offsets, (const u64*) queries, (u64) nq,
                      (u64*) out);
   return hipGetLastError();
@@ -2130,7 +2181,7 @@ hipError_t launch_wr_select_byte(const uint64_t* dense, uint64_t n, const uint64
                                  uint64_t* out, hipStream_t s) {
   const u64 nchunks = (n + kDecodeTile - 1) / kDecodeTile;
   if (nq == 0 || nchunks == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_wr_select_byte, dim3((unsigned) ((nq + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(k_wr_select_byte, dim3((unsigned) ((nq * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      s, (const u64*) dense, (u64) n, (const u64*) chunk_offsets, nchunks,
                      is_string ? 1u : 0u, (const u64*) queries, (u64) nq, (u64*) out);
   return hipGetLastError();

@@ -24,6 +24,8 @@ if [ "$PART" = 1 ]; then
   b config4_string_keys --steps 10 --warmup 2 --workload config4s
   b config5 --steps 20 --warmup 3 --workload config5
   b config5w --steps 10 --warmup 2 --workload config5w --no-cpu-baseline
+  echo "[measure] device writer"; date
+  python scripts/bench_writer.py 1e8 > "$OUT/bench_writer.jsonl" 2> "$OUT/bench_writer.err" || tail -5 "$OUT/bench_writer.err"
 else
   cd /tmp; export TMPDIR=/tmp
   kt() {  # kt <name> <bench args...>
