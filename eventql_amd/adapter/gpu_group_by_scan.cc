@@ -7,6 +7,8 @@
 #include <eventql/sql/runtime/ValueExpression.h>
 #include <eventql/sql/runtime/query_cache.h>
 #include <eventql/sql/runtime/runtime.h>
+#include <eventql/sql/statements/select/limit.h>
+#include <eventql/sql/statements/select/orderby.h>
 #include <eventql/util/exception.h>
 #include <eventql/util/io/inputstream.h>
 #include <eventql/util/io/outputstream.h>
@@ -172,6 +174,48 @@ void GpuGroupByScan::enableQueryCache(const SHA1Hash& key,
 
 Option<SHA1Hash> GpuGroupByScan::getCacheKey() const { return cache_key_; }
 
+bool GpuGroupByScan::setOrder(const std::vector<csql::OrderByNode::SortSpec>& specs,
+                              std::string* why) {
+  if (partial_) { /* (its rows are group keys + saved states: nothing to order by) */
+    *why = "partial aggregate";
+    return false;
+  }
+  std::vector<std::unique_ptr<LoweredProgram>> programs;
+  std::vector<evql_sort_spec_t> lowered;
+  for (const auto& ss : specs) {
+    /* compiled exactly like scheduler.cc:101-104; X_INPUT i = output column i */
+    csql::ValueExpression compiled = txn_->getCompiler()->buildValueExpression(txn_, ss.expr);
+    programs.emplace_back(new LoweredProgram());
+    if (!lowerProgram(compiled.program(), programs.back().get(), why)) return false;
+    evql_sort_spec_t sp;
+    sp.expr = programs.back()->c;
+    sp.descending = ss.descending ? 1 : 0;
+    lowered.push_back(sp);
+  }
+  int rc = evql_query_set_order(query_, lowered.data(), (uint32_t) lowered.size(), -1, 0);
+  if (rc != EVQL_OK) {
+    *why = std::string(rc == EVQL_ENOTSUP ? "ENOTSUP: " : "") + evql_last_error();
+    return false;
+  }
+  sort_programs_ = std::move(programs);
+  sort_specs_ = std::move(lowered);
+  return true;
+}
+
+bool GpuGroupByScan::setLimit(size_t limit, size_t offset, std::string* why) {
+  if (partial_) {
+    *why = "partial aggregate";
+    return false;
+  }
+  int rc = evql_query_set_order(query_, sort_specs_.data(), (uint32_t) sort_specs_.size(),
+                                (int64_t) limit, (uint64_t) offset);
+  if (rc != EVQL_OK) {
+    *why = std::string(rc == EVQL_ENOTSUP ? "ENOTSUP: " : "") + evql_last_error();
+    return false;
+  }
+  return true;
+}
+
 GpuGroupByScan::~GpuGroupByScan() { evql_query_destroy(query_); }
 
 int GpuGroupByScan::heartbeat(void* self) {
@@ -325,6 +369,7 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
     RAISE(kRuntimeError, evql_last_error());
   }
   auto op = new GpuGroupByScan(txn, execution_context, q);
+  if (partial) op->markPartial();
   if (partial && !version_tag.empty()) {
     /* PartialGroupByExpression::getCacheKey = SHA1(input key + fingerprint of the
      * group-by's expressions) (groupby.cc:474-482, server/sql/scheduler.cc:85-103);
@@ -382,6 +427,56 @@ ScopedPtr<csql::TableExpression> GpuScheduler::buildSequentialScan(
     if (opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
   }
   return csql::DefaultScheduler::buildSequentialScan(txn, execution_context, node);
+}
+
+/* ORDER BY / LIMIT directly above a lowered GROUP BY: into the operator (its top-k runs
+ * on the device over the dense group records); anything else: the reference's operators
+ * stacked on the input that was just built (scheduler.cc:36-49, 95-132) */
+ScopedPtr<csql::TableExpression> GpuScheduler::buildOrderByExpression(
+    csql::Transaction* txn, csql::ExecutionContext* execution_context,
+    RefPtr<csql::OrderByNode> node) {
+  if (!opts_.lower_group_by || !opts_.fuse_order_by) {
+    return csql::DefaultScheduler::buildOrderByExpression(txn, execution_context, node);
+  }
+  auto input = buildTableExpression(
+      txn, execution_context, node->inputTable().asInstanceOf<csql::TableExpressionNode>());
+  std::string why = "input is not the GPU operator";
+  auto gpu = dynamic_cast<GpuGroupByScan*>(input.get());
+  const bool fused = gpu && gpu->setOrder(node->sortSpecs(), &why);
+  decisions_.push_back(Decision{"orderby", fused, fused ? "" : why});
+  if (fused) return input;
+  Vector<csql::OrderByExpression::SortExpr> sort_exprs;
+  Vector<csql::PureSFunctionPtr> comparators;
+  for (const auto& ss : node->sortSpecs()) {
+    csql::OrderByExpression::SortExpr se;
+    se.descending = ss.descending;
+    se.expr = txn->getCompiler()->buildValueExpression(txn, ss.expr);
+    const csql::SymbolTableEntry* symbol = nullptr;
+    auto rc = txn->getSymbolTable()->resolve(
+        "cmp", {se.expr.getReturnType(), se.expr.getReturnType()}, &symbol, false);
+    if (!rc.isSuccess()) RAISE(kRuntimeError, rc.getMessage());
+    comparators.emplace_back(symbol->getFunction()->vtable.call);
+    sort_exprs.emplace_back(std::move(se));
+  }
+  return mkScoped(new csql::OrderByExpression(txn, execution_context, std::move(sort_exprs),
+                                              comparators, std::move(input)));
+}
+
+ScopedPtr<csql::TableExpression> GpuScheduler::buildLimit(
+    csql::Transaction* txn, csql::ExecutionContext* execution_context,
+    RefPtr<csql::LimitNode> node) {
+  if (!opts_.lower_group_by || !opts_.fuse_order_by) {
+    return csql::DefaultScheduler::buildLimit(txn, execution_context, node);
+  }
+  auto input = buildTableExpression(
+      txn, execution_context, node->inputTable().asInstanceOf<csql::TableExpressionNode>());
+  std::string why = "input is not the GPU operator";
+  auto gpu = dynamic_cast<GpuGroupByScan*>(input.get());
+  const bool fused = gpu && gpu->setLimit(node->limit(), node->offset(), &why);
+  decisions_.push_back(Decision{"limit", fused, fused ? "" : why});
+  if (fused) return input;
+  return mkScoped(new csql::LimitExpression(execution_context, node->limit(), node->offset(),
+                                            std::move(input)));
 }
 
 }  // namespace evql_adapter

@@ -22,6 +22,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <eventql/sql/qtree/LimitNode.h>
+#include <eventql/sql/qtree/OrderByNode.h>
 #include <eventql/sql/scheduler.h>
 #include <eventql/sql/table_expression.h>
 #include <eventql/sql/transaction.h>
@@ -116,6 +118,14 @@ public:
   void enableQueryCache(const SHA1Hash& key, std::shared_ptr<std::atomic<uint64_t>> hit_counter);
   Option<SHA1Hash> getCacheKey() const override;
 
+  /* ORDER BY .. LIMIT fused into the operator (OrderByExpression::execute,
+   * orderby.cc:60-160; LimitExpression::nextBatch, limit.cc:52-125): the sort
+   * expressions are programs over this operator's output columns.  false => not
+   * fusable (*why says what); the caller then stacks the CPU operators on top */
+  void markPartial() { partial_ = true; }
+  bool setOrder(const std::vector<csql::OrderByNode::SortSpec>& specs, std::string* why);
+  bool setLimit(size_t limit, size_t offset, std::string* why);
+
 private:
   static int heartbeat(void* self);
   static const size_t kMaxCachedBytes = 256u << 20;
@@ -127,6 +137,7 @@ private:
   csql::ExecutionContext* execution_context_;
   evql_query_t* query_;
   bool completed_;
+  bool partial_ = false;
   Option<SHA1Hash> cache_key_;
   std::shared_ptr<std::atomic<uint64_t>> cache_hits_;
   bool from_cache_;
@@ -134,12 +145,15 @@ private:
   size_t recorded_bytes_;
   size_t replay_pos_;
   std::vector<CachedBatch> batches_;
+  std::vector<std::unique_ptr<LoweredProgram>> sort_programs_;
+  std::vector<evql_sort_spec_t> sort_specs_;
 };
 
 struct GpuSchedulerOptions {
   GpuSchedulerOptions() : lower_group_by(true), lower_scans(false), partial(false),
-                          strict(false) {}
+                          strict(false), fuse_order_by(true) {}
   bool lower_group_by; /* GroupByExpression + scan -> one fused operator */
+  bool fuse_order_by;  /* ORDER BY / LIMIT directly above it -> into the operator */
   bool lower_scans;    /* bare FastCSTableScan / CSTableScan -> GPU scan operator */
   bool partial;        /* build PartialGroupByExpression's twin (a data node) */
   bool strict;         /* tests: RAISE instead of falling back to the CPU operators */
@@ -167,6 +181,14 @@ protected:
   ScopedPtr<csql::TableExpression> buildSequentialScan(
       csql::Transaction* txn, csql::ExecutionContext* execution_context,
       RefPtr<csql::SequentialScanNode> node) override;
+
+  ScopedPtr<csql::TableExpression> buildOrderByExpression(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::OrderByNode> node) override;
+
+  ScopedPtr<csql::TableExpression> buildLimit(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::LimitNode> node) override;
 
   /* nullptr => keep the CPU operators */
   csql::TableExpression* tryLower(csql::Transaction* txn,

@@ -207,3 +207,47 @@ def test_partial_operator_uses_the_query_cache():
         for r in (res[1], res[3], res[4], res[5]):
             assert probe_rows(r) == base
         assert probe_rows(res[2]) != base
+
+
+@pytest.mark.skipif(not os.path.exists(PROBE), reason="oracle/_ref/csql_probe not built "
+                    "(needs /root/reference at build time)")
+def test_order_by_and_limit_are_fused_into_the_operator():
+    """ORDER BY / LIMIT above a lowered GROUP BY (OrderByExpression, orderby.cc:60-160;
+    LimitExpression, limit.cc:52-125): GpuScheduler pushes them into the operator
+    (evql_query_set_order: device top-k over the group records); the rows come out in
+    the reference's order.  Sort keys are unique, so the order is fully specified."""
+    img, _, kind = refcases.table_image("survey")
+    # (every aggregated column also appears in WHERE: the reference's scan resolves only
+    # the columns its predicate names, see sqlgen.make_runnable)
+    queries = [
+        "select k, sum(a), count(1) from t where a >= 0 group by k order by k limit 10;",
+        "select k, sum(a) as sa, count(1) from t where a >= 0 group by k order by k desc limit 7 offset 3;",
+        "select k, sum(a) as sa, count(1) as c from t where a > 1000 group by k order by sa desc, k limit 25;",
+        "select k, count(1) as c, sum(a) as sa from t where a >= 0 group by k order by c, k desc limit 12 offset 990;",
+        "select k, sum(a) as sa from t where a >= 0 group by k order by k;",
+        # a sort expression the device cannot read from a group record: CPU OrderBy on top
+        "select k, sum(a) as sa from t where a >= 0 group by k order by sa % 7, k limit 9;",
+    ]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "t.cst")
+        with open(path, "wb") as f:
+            f.write(img)
+        out = {}
+        for mode in ("cpu", "gpu"):
+            cmds = ["TABLE t %s %s" % (path, kind), "ROWS on", "MODE " + mode] + ["SQL " + q for q in queries]
+            p = subprocess.run([PROBE], input="\n".join(cmds) + "\n", capture_output=True,
+                               text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            out[mode] = [json.loads(l) for l in p.stdout.splitlines() if l.strip()]
+    for q, c, g in zip(queries, out["cpu"], out["gpu"]):
+        assert c["ok"] and g["ok"], (q, c.get("error"), g.get("error"))
+        assert g["types"] == c["types"], q
+        assert g["rows"] == c["rows"], q          # same rows in the same ORDER
+        d = {x["node"]: x["lowered"] for x in g["decisions"]}
+        assert d.get("groupby") is True, (q, g["decisions"])
+        if "% 7" in q:
+            assert d.get("orderby") is False, (q, g["decisions"])
+        else:
+            assert d.get("orderby") is True, (q, g["decisions"])
+            if "limit" in q:
+                assert d.get("limit") is True, (q, g["decisions"])
