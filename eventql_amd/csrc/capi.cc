@@ -654,8 +654,9 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   if (q->kp.need_first_row) {
     // a first-row index means something only inside the table that produced it:
-    // key / select values of such plans travel with evql_query_export_resolved
-    return fail(EVQL_ENOTSUP, "plan reads first-row values: use evql_query_export_resolved");
+    // the key / select values of such plans travel inside the records of
+    // evql_query_exchange (exchange.cc, k_resolve_records)
+    return fail(EVQL_ENOTSUP, "plan reads first-row values: merge it with evql_query_exchange");
   }
   hipStream_t s = q->ctx->stream;
   if (!q->d_gtab || !q->d_counters) return fail(EVQL_EARG, "execute() was not called");
@@ -685,6 +686,9 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
 int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n_groups) {
   API_TRY
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
+  if (q->kp.need_first_row) {
+    return fail(EVQL_ENOTSUP, "plan reads first-row values: merge it with evql_query_exchange");
+  }
   hipStream_t s = q->ctx->stream;
   {
     // (also moves the dense records of the partitioned path into the table)

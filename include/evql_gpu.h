@@ -527,7 +527,11 @@ int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out);
 int evql_query_export_groups(evql_query_t* q, void* device_dst,
                              uint64_t max_groups, uint64_t* n_groups);
 /* merge dense records produced by evql_query_export_groups on another
- * partition / rank into this query's table (mergeInstance per aggregate) */
+ * partition / rank into this query's table (mergeInstance per aggregate); the table
+ * is regrown first when the incoming groups would not fit.  Both answer EVQL_ENOTSUP
+ * for plans whose records name a first ROW (string / multi-column keys, non-aggregate
+ * select expressions) -- a row index means nothing outside the table that produced
+ * it; evql_query_exchange carries the values themselves -- and for count_distinct. */
 int evql_query_import_groups(evql_query_t* q, const void* device_src,
                              uint64_t n_groups);
 uint32_t evql_query_record_words(const evql_query_t* q);
