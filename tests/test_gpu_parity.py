@@ -1054,6 +1054,48 @@ def test_full_size_high_cardinality_properties(ctx):
     t.close()
 
 
+def test_full_size_string_key_properties(ctx):
+    """BASELINE config 4 as written -- 1.25e8 rows, 1e7 STRING keys ("g" + u): value
+    boundaries and hashes found on the device, partitioned path with 32-byte tuples,
+    first-row strings gathered at emission -- against totals and, group by group on a
+    1111-key slice, against the LDS path of the same query with a WHERE"""
+    n, n_keys = 125_000_000, 10_000_000
+    t = B.string_key_table(ctx, n, n_keys, seed=77)
+    S = B.STRING_KEY_SCHEMA
+    plan = B.config4s(groups_hint=n_keys)
+    q = t.query(plan)
+    assert "evql_part_refine" in q.kernel_source()
+    q.execute()
+    st = q.stats()
+    assert n_keys - 200 < st["num_groups"] <= n_keys and st["rows_passed"] == n
+    allg = q.fetch_all(1 << 20)
+    q.close()
+    assert allg.nrows == st["num_groups"]
+    rows = allg.rows()
+    by_key = {r[0]: r for r in rows}
+    assert len(by_key) == allg.nrows                      # every key once
+    assert all(k[:1] == b"g" for k in list(by_key)[:1000])
+    tot = t.query(Plan(S, select=[count(1), sum_(col("a")), sum_(col("v"))])).run().rows()[0]
+    assert sum(r[2] for r in rows) == n == tot[0]
+    assert sum(r[1] for r in rows) == tot[1]
+    sv = sum(r[3] for r in rows)
+    assert abs(sv - tot[2]) <= 1e-9 * abs(tot[2])
+    # keys g9999, g9999x, g9999xx, g9999xxx through the LDS path (bytewise predicates)
+    s_ = col("s")
+    q = t.query(Plan(S, select=[s_, sum_(col("a")), count(1), sum_(col("v"))], group_by=[s_],
+                     where=(s_ >= "g9999") & (s_ < "g9999:"), groups_hint=2000))
+    assert "evql_part_refine" not in q.kernel_source()
+    small = q.run()
+    q.close()
+    want = [k for k in by_key if k.startswith(b"g9999")]
+    assert small.nrows == len(want) and 1000 < small.nrows <= 1111
+    for k, sa, c, v in small.rows():
+        r = by_key[k]
+        assert (sa, c) == (r[1], r[2]), k
+        assert abs(v - r[3]) <= 1e-9 * abs(v), k
+    t.close()
+
+
 def test_full_size_properties(ctx):
     """BASELINE sizes (1e9 rows, config 3): size-independent properties"""
     n = 1_000_000_000
