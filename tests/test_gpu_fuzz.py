@@ -109,7 +109,8 @@ class Gen:
             kw["where"] = self.boolean()
         if r.random() < 0.2:
             kw["row_end"] = r.choice(row_ends)
-        kw["groups_hint"] = r.choice([0, 0, 10, 1000, 100000])
+        # (100000: one scatter level; 3000000: coarse + refine, 32-bit tuple members)
+        kw["groups_hint"] = r.choice([0, 0, 10, 1000, 100000, 3000000])
         if self.nrows and r.random() < 0.15:
             # external row filter (LSM skip / update filter, CSTableScan.cc:826-833)
             kw["row_filter"] = np.random.default_rng(r.randrange(1 << 30)).random(self.nrows) < 0.6
