@@ -152,6 +152,13 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a
+    # version banner on stdout when a communicator is created): from here on file
+    # descriptor 1 is stderr, and the result line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import eventql_amd as E
     from eventql_amd import bench_plans as B, capi as K, distributed as D, synth
 
@@ -429,7 +436,8 @@ def main():
             out["config"]["flattened_rows_per_gpu"] = int(stats["rows_scanned"])
             out["config"]["encodings"] = "levels bit-packed, position UINT32_BITPACKED(4b), price LEB128"
             out["unit"] = "records/s"
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
