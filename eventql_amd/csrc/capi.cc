@@ -10,7 +10,7 @@
 namespace evql {
 const std::string& last_error();
 void set_cache_dir(const std::string& d);
-Status compile_to_code_object(const std::string& source, std::vector<char>* code);
+Status compile_to_code_object(const std::string& source, std::vector<char>* code, bool use_cache);
 Status table_from_image(evql_ctx* ctx, const void* image, size_t len, bool keep_host,
                         evql_table** out);
 Status query_prepare(evql_query* q);
@@ -769,7 +769,7 @@ int evql_compile_only(const evql_plan_desc_t* plan, const evql_column_info_t* co
   }
   q.source = generate_kernel_source(q.kp);
   std::vector<char> code;
-  st = compile_to_code_object(q.source, &code);
+  st = compile_to_code_object(q.source, &code, true);
   if (!st.ok()) return ret(st);
   if (code_size) *code_size = code.size();
   return EVQL_OK;

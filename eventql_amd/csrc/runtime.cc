@@ -1,6 +1,8 @@
 // runtime.cc -- HIP device context, table residency in HBM, JIT of the fused
 // kernel, execution and result emission.
 #include "runtime.h"
+#include <unistd.h>
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -47,16 +49,29 @@ static std::string hex_digest(const std::string& s) {
 static const char* kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics",
                                         "-ffp-contract=off", "-std=c++17"};
 
-Status compile_to_code_object(const std::string& source, std::vector<char>* code) {
+// an ELF header and, where it can be checked cheaply, a section header table inside
+// the file: what a complete code object of the cache looks like
+static bool plausible_code_object(const std::vector<char>& c) {
+  if (c.size() < 64 || memcmp(c.data(), "\x7f" "ELF", 4) != 0) return false;
+  uint64_t shoff;
+  uint16_t shentsize, shnum;
+  memcpy(&shoff, c.data() + 0x28, 8);
+  memcpy(&shentsize, c.data() + 0x3a, 2);
+  memcpy(&shnum, c.data() + 0x3c, 2);
+  return shoff <= c.size() && uint64_t(shentsize) * shnum <= c.size() - shoff;
+}
+
+Status compile_to_code_object(const std::string& source, std::vector<char>* code, bool use_cache) {
   const std::string full = std::string(device_library_source()) + "\n" + source;
   std::string key = hex_digest(full);
   std::string cache_file;
   if (!g_cache_dir.empty()) {
     cache_file = g_cache_dir + "/" + key + ".hsaco";
     std::ifstream f(cache_file, std::ios::binary);
-    if (f) {
+    if (f && use_cache) {
       code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-      if (!code->empty()) return Status();
+      if (plausible_code_object(*code)) return Status();
+      code->clear();
     }
   }
   hiprtcProgram prog;
@@ -81,11 +96,15 @@ Status compile_to_code_object(const std::string& source, std::vector<char>* code
   hiprtcDestroyProgram(&prog);
   if (!cache_file.empty()) {
     mkdir(g_cache_dir.c_str(), 0755);
-    std::string tmp = cache_file + ".tmp";
+    // (several processes -- one per GPU -- compile the same plan at the same time: each
+    // writes a file of its own and renames it into place)
+    static std::atomic<unsigned> serial{0};
+    const std::string tmp = cache_file + "." + std::to_string(long(getpid())) + "." +
+                            std::to_string(serial.fetch_add(1)) + ".tmp";
     std::ofstream f(tmp, std::ios::binary);
     f.write(code->data(), std::streamsize(code->size()));
     f.close();
-    rename(tmp.c_str(), cache_file.c_str());
+    if (!f || rename(tmp.c_str(), cache_file.c_str()) != 0) remove(tmp.c_str());
   }
   return Status();
 }
@@ -100,11 +119,18 @@ Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out, boo
     }
   }
   std::vector<char> code;
-  Status st = compile_to_code_object(source, &code);
+  Status st = compile_to_code_object(source, &code, true);
   if (!st.ok()) return st;
   out->code_size = code.size();
   if (load_module) {
-    HIP_TRY(hipModuleLoadData(&out->mod, code.data()));
+    if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) {
+      // a damaged cache file: compile again (and replace it)
+      (void) hipGetLastError();
+      st = compile_to_code_object(source, &code, false);
+      if (!st.ok()) return st;
+      out->code_size = code.size();
+      HIP_TRY(hipModuleLoadData(&out->mod, code.data()));
+    }
     HIP_TRY(hipModuleGetFunction(&out->fn, out->mod, "evql_scan_agg"));
     if (source.find("evql_part_aggregate") != std::string::npos) {
       HIP_TRY(hipModuleGetFunction(&out->fn_count, out->mod, "evql_part_count"));

@@ -193,3 +193,32 @@ def test_plan_builder_matches_reference_compiler_layout():
         Plan(S, select=[count(1)], where=col("a") > 1.5)  # gt<uint64,float64> is a type error
     with pytest.raises(CompileError):
         Plan(S, select=[Agg("max_by", col("a"))])
+
+
+def _compile_into(d):
+    import eventql_amd as E2
+    from eventql_amd import bench_plans as B2
+    return E2.compile_only(B2.config2(), B2.PLAIN_COLUMNS, d)
+
+
+def test_kernel_cache_survives_damage_and_concurrent_writers(built, tmp_path):
+    """one process per GPU compiles the same plan at the same time: every writer renames
+    a file of its own into place; a truncated / foreign cache file is compiled again"""
+    import glob
+    import multiprocessing as mp
+    d = str(tmp_path / "kc")
+    os.makedirs(d)
+    with mp.get_context("spawn").Pool(3) as pool:
+        sizes = pool.map(_compile_into, [d] * 3)
+    assert len(set(sizes)) == 1 and sizes[0] > 1000
+    files = glob.glob(d + "/*")
+    assert len(files) == 1 and files[0].endswith(".hsaco"), files   # no stray .tmp files
+    assert os.path.getsize(files[0]) == sizes[0]
+    with open(files[0], "r+b") as f:
+        f.truncate(100)                     # an ELF header without its sections
+    assert E.compile_only(B.config2(), B.PLAIN_COLUMNS, d) == sizes[0]
+    assert os.path.getsize(files[0]) == sizes[0]
+    with open(files[0], "wb") as f:
+        f.write(b"not a code object")
+    assert E.compile_only(B.config2(), B.PLAIN_COLUMNS, d) == sizes[0]
+    assert os.path.getsize(files[0]) == sizes[0]
