@@ -4,7 +4,8 @@ engine (oracle/_ref/csql_probe, built from /root/reference by oracle/ref_csql/bu
 once with its CPU operators (MODE cpu) and once with the GPU operator plugged in (MODE gpu);
 rows must be identical.  Same generators as the committed fixtures (tests/refcases.py),
 other seeds; flat tables and the two nested ones (Dremel scans).
-usage: soak_reference_differential.py <first seed offset> <count> [families, e.g. items,testtbl]"""
+usage: soak_reference_differential.py <first seed offset> <count> [families, e.g. items,testtbl
+       | all] [partial]"""
 import json
 import os
 import subprocess
@@ -64,8 +65,12 @@ def cases(first, count):
     return out
 
 
+PARTIAL = len(sys.argv) > 4 and sys.argv[4] == "partial"
+
+
 def run(mode, path, kind, sqls):
-    cmds = ["TABLE t %s %s" % (path, kind), "ROWS on", "MODE " + mode]
+    # partial: PartialGroupByExpression's rows (group key, saved states) as bytes
+    cmds = ["TABLE t %s %s" % (path, kind), "ROWS on", "MODE " + mode + (" partial" if PARTIAL else "")]
     if mode == "cpu" and kind == "dremel":
         cmds.append("DUMP on")
     cmds += ["SQL " + s for s in sqls]
@@ -86,7 +91,7 @@ def main():
     total = lowered = errors_equal = undefined = 0
     bad = []
     with tempfile.TemporaryDirectory() as tmp:
-        want = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+        want = sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] != "all" else None
         for table, cs in cases(first, count).items():
             if want and table not in want:
                 continue
@@ -105,6 +110,8 @@ def main():
                     continue
                 total += 1
                 d = [x for x in b.get("decisions", []) if x["node"] == "groupby"]
+                if PARTIAL and not (d and d[0]["lowered"]):
+                    continue  # (the probe's CPU fallback in gpu mode is the final operator)
                 lowered += 1 if d and d[0]["lowered"] else 0
                 if not a["ok"] or not b["ok"]:
                     # an error is an error in both (division by zero, ...)
