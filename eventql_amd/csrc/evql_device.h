@@ -341,6 +341,21 @@ __device__ __forceinline__ void evql_atomic(u64* p, u64 v) {
 // (EVQL_EMPTY = free), claimed with a 64-bit compare-and-swap.
 // ---------------------------------------------------------------------------
 
+// A fresh read of an LDS word that other waves update.  NOT a volatile access: address
+// space inference leaves volatile loads alone, so `*(volatile u64*) &lds[s]` stayed a
+// FLAT load -- it counts in vmcnt as well as lgkmcnt, and the s_waitcnt vmcnt(0) behind
+// every probe made each wave wait for ALL of its tile's column loads before the first
+// row could be evaluated (ISA of round 2: 16 flat_load_dwordx2 per tile body).  A relaxed
+// atomic load is inferred to LDS (ds_read_b64) and the column loads stay in flight while
+// rows are evaluated: 10-bit config 2 2.18 -> 1.87 ms, config 3 over 16-bit pages
+// 0.386 -> 0.360 ms.
+__device__ __forceinline__ u64 evql_lds_peek(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ u32 evql_lds_peek32(const u32* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // LDS table: returns the slot or -1 when no slot was found within MAXP probes
 template <int MAXP>
 __device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32 h) {
@@ -350,7 +365,7 @@ __device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32
   // mixed-hash linear chain.
   u32 s = (u32) ident & mask;
   {
-    u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);
+    u64 cur = evql_lds_peek(&keys[s]);
     if (cur == ident) return (int) s;
     if (cur == EVQL_EMPTY) {
       u64 old = atomicCAS(&keys[s], EVQL_EMPTY, ident);
@@ -360,7 +375,7 @@ __device__ __forceinline__ int evql_lds_find(u64* keys, u32 mask, u64 ident, u32
   s = h & mask;
 #pragma unroll 1
   for (int probe = 0; probe < MAXP; ++probe) {
-    u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);
+    u64 cur = evql_lds_peek(&keys[s]);
     if (cur == ident) return (int) s;
     if (cur == EVQL_EMPTY) {
       u64 old = atomicCAS(&keys[s], EVQL_EMPTY, ident);
@@ -409,10 +424,10 @@ __device__ __forceinline__ int evql_lds_find2(u64* keys, u64* keys2, u32 mask, u
   u32 s = (u32) ident & mask;
 #pragma unroll 1
   for (int probe = 0; probe <= MAXP; ++probe) {
-    u64 cur = *reinterpret_cast<volatile u64*>(&keys[s]);
+    u64 cur = evql_lds_peek(&keys[s]);
     if (cur == EVQL_EMPTY) cur = atomicCAS(&keys[s], EVQL_EMPTY, ident);
     if (cur == EVQL_EMPTY || cur == ident) {
-      u64 c2 = *reinterpret_cast<volatile u64*>(&keys2[s]);
+      u64 c2 = evql_lds_peek(&keys2[s]);
       if (c2 == EVQL_EMPTY) c2 = atomicCAS(&keys2[s], EVQL_EMPTY, ident2);
       if (c2 == EVQL_EMPTY || c2 == ident2) return (int) s;
     }
