@@ -24,7 +24,10 @@ SEEDS = range(int(os.environ.get("EVQL_FUZZ_FROM", "0")), int(os.environ.get("EV
 
 
 class Gen:
+    two_level_hints = False
+
     def __init__(self, seed, uint_cols, float_cols, bool_cols, key_cols, first_cols, lits):
+        self.seed = seed
         self.r = random.Random(seed)
         self.uint_cols, self.float_cols, self.bool_cols = uint_cols, float_cols, bool_cols
         self.key_cols, self.first_cols, self.lits = key_cols, first_cols, lits
@@ -109,8 +112,13 @@ class Gen:
             kw["where"] = self.boolean()
         if r.random() < 0.2:
             kw["row_end"] = r.choice(row_ends)
-        # (100000: one scatter level; 3000000: coarse + refine, 32-bit tuple members)
-        kw["groups_hint"] = r.choice([0, 0, 10, 1000, 100000, 3000000])
+        kw["groups_hint"] = r.choice([0, 0, 10, 1000, 100000])
+        # (100000: one scatter level of the partitioned path; the fuzz tests of this file
+        # send every other such plan through coarse + refine instead.  Decided without the
+        # generator's random stream: tests/refcases.py derives the committed reference
+        # fixtures from this class, seed for seed.)
+        if self.two_level_hints and kw["groups_hint"] == 100000 and self.seed % 2:
+            kw["groups_hint"] = 3000000
         if self.nrows and r.random() < 0.15:
             # external row filter (LSM skip / update filter, CSTableScan.cc:826-833)
             kw["row_filter"] = np.random.default_rng(r.randrange(1 << 30)).random(self.nrows) < 0.6
@@ -205,6 +213,7 @@ def mixed(ctx):
 def test_random_plan(mixed, seed):
     t, img = mixed
     g = Gen(seed, **MIXED)
+    g.two_level_hints = True
     g.nrows = 300_000
     kw = g.plan_kwargs([1, 4097, 131073, 250000])
     run_case(t, img, T.MIXED_SCHEMA, kw, partial_too=True)
@@ -273,6 +282,7 @@ def test_random_nested_plan(nested, seed):
     t, img, schema, cols = ((ti, img_items, N.ITEMS_SCHEMA, items) if which == 0 else
                             (tf, img_fix, N.NESTED_SCHEMA, fixture))
     g = NestedGen(2000 + seed, **cols)
+    g.two_level_hints = True
     if which == 0:
         g.leaf_uint, g.leaf_bool = ["items.position", "items.price"], []
     else:
@@ -333,6 +343,7 @@ def ranges(ctx):
 def test_random_plan_full_range_columns(ranges, seed):
     t, img = ranges
     g = Gen(1000 + seed, **RANGES)
+    g.two_level_hints = True
     g.nrows = 200_000
     kw = g.plan_kwargs([1, 4097, 131073, 150000])
     run_case(t, img, RANGES_SCHEMA, kw, partial_too=True)
