@@ -97,6 +97,7 @@ struct KernelPlan {
 // launch shape for `hint` expected groups (planner.cc)
 void choose_launch_shape(KernelPlan* kp, uint64_t hint);
 uint64_t lds_table_max_slots(const KernelPlan& kp);
+extern const uint64_t kPartitionAboveSlots;  // partitioned path for hint > this * LDS slots
 bool partitioned_path_possible(const KernelPlan& kp);
 
 // the generated translation unit (device library excluded)

@@ -135,6 +135,9 @@ bool partitioned_path_possible(const KernelPlan& kp) {
          kp.n_distinct == 0;
 }
 
+// the partitioned path takes over as soon as the expected groups exceed the LDS slots
+const uint64_t kPartitionAboveSlots = 1;
+
 void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
   KernelPlan& kp = *kpp;
   kp.block = 256;
@@ -142,6 +145,20 @@ void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
   // loads in flight per lane = columns x unroll; ~16 saturate HBM (measured: 2
   // columns 2.54 ms at unroll 4, 2.43 ms at unroll 8; 4 columns spill at 8)
   kp.unroll = kp.cols.size() <= 2 ? 8 : 4;
+  {
+    // A 1024-thread workgroup leaves each wave 128 VGPRs.  Rough budget: ~50 for the
+    // loop itself, 4 (+1 with tags) per column and unroll step for the tile, 4 per update
+    // word (row outputs + the lane-private run accumulators).  Plans beyond it start with
+    // fewer unroll steps; the runtime halves again if the compiled kernel still reports
+    // scratch memory (compile_plan_kernels) -- measured on a 12-aggregate plan over
+    // config 3's table: 2.66 ms spilling at unroll 4, 1.88 ms at unroll 1.
+    int upd = 0;
+    for (const auto& a : kp.aggs) upd += a.nwords;
+    int per_step = 0;
+    for (const auto& c : kp.cols) per_step += c.has_tags ? 5 : 4;
+    // (the estimate runs ~15 high: config 3 -- 4 columns, 3 update words -- compiles to 109)
+    while (kp.unroll > 1 && 50 + per_step * kp.unroll + 4 * upd > 144) kp.unroll /= 2;
+  }
   // (narrow re-encoded columns at unroll 8 spill: config3l 0.39 ms at 4, 0.72 ms at 8)
   kp.lds_slots = 0;
   if (kp.key_mode == KEY_NONE) return;
@@ -154,9 +171,13 @@ void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
   // works (4000 dense groups in 4096 slots: 0.63 ms vs 24 ms HBM-only for 2e8
   // rows); a workgroup whose table does thrash switches itself to the HBM
   // table (`bypass`).  Only far beyond the LDS capacity is the table skipped.
-  if (hint > 8 * smax && partitioned_path_possible(kp)) {
-    // high cardinality: one random HBM atomic per state word per row tops out at
-    // the chip's scattered-atomic rate (~2e10/s measured).  Instead the passing
+  if (hint > kPartitionAboveSlots * smax && partitioned_path_possible(kp)) {
+    // more groups than LDS slots: the rows of the groups that find no slot would go to
+    // the HBM table with one random atomic per state word, which tops out at the
+    // chip's scattered-atomic rate (~2e10/s measured) -- with 3 state words, 13 % of
+    // the rows overflowing already cost as much as partitioning all of them (3 tuple
+    // passes at ~5 TB/s), and a plan with 20 state words whose 1000 groups met a
+    // 256-slot table ran 346 ms per 2e8 rows.  Instead the passing
     // rows are radix-partitioned into buckets small enough for the LDS table
     // (streaming traffic) and every bucket is aggregated in LDS.
     kp.partitioned = true;

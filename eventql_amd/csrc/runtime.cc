@@ -1398,6 +1398,28 @@ static Status compile_plan_kernels(evql_query* q) {
   q->source = generate_kernel_source(q->kp);
   Status st = compile_kernel(ctx, q->source, &q->module, true);
   if (!st.ok()) return st;
+  // A plan with many columns / state words can outgrow the 128 VGPRs a 1024-thread
+  // workgroup leaves each wave: the scan kernel then keeps part of a tile in scratch
+  // memory.  Fewer unroll steps per tile (fewer loads in flight, no scratch) are tried
+  // until the kernel fits.
+  while (q->kp.unroll > 1) {
+    // (the kernels that hold a tile in registers: the fused scan and, for partitioned
+    // plans, count and scatter -- only the latter run then)
+    int scratch = 0;
+    hipFunction_t fns[3] = {q->kp.partitioned ? nullptr : q->module.fn, q->module.fn_count,
+                            q->module.fn_scatter};
+    for (hipFunction_t f : fns) {
+      int sc = 0;
+      if (f && hipFuncGetAttribute(&sc, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) == hipSuccess) {
+        scratch = std::max(scratch, sc);
+      }
+    }
+    if (scratch == 0) break;
+    q->kp.unroll /= 2;
+    q->source = generate_kernel_source(q->kp);
+    st = compile_kernel(ctx, q->source, &q->module, true);
+    if (!st.ok()) return st;
+  }
   // persistent grid: one wave of workgroups per CU slot
   int per_cu = 1;
   hipError_t oe = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, q->module.fn,
@@ -1455,7 +1477,7 @@ static Status probe_cardinality(evql_query* q) {
   const uint64_t hint = uint64_t(g_est * 1.25) + 16;  // headroom for the estimate's error
   q->groups_hint = hint;
   q->stats.estimated_groups = hint;
-  if (hint > 8 * lds_table_max_slots(q->kp) && partitioned_path_possible(q->kp)) {
+  if (hint > kPartitionAboveSlots * lds_table_max_slots(q->kp) && partitioned_path_possible(q->kp)) {
     choose_launch_shape(&q->kp, hint);
     return compile_plan_kernels(q);
   }

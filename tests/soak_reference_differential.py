@@ -4,7 +4,7 @@ engine (oracle/_ref/csql_probe, built from /root/reference by oracle/ref_csql/bu
 once with its CPU operators (MODE cpu) and once with the GPU operator plugged in (MODE gpu);
 rows must be identical.  Same generators as the committed fixtures (tests/refcases.py),
 other seeds; flat tables and the two nested ones (Dremel scans).
-usage: soak_reference_differential.py <first seed offset> <count> [families, e.g. items,testtbl
+usage: tests/soak_reference_differential.py <first seed offset> <count> [families, e.g. items,testtbl
        | all] [partial]"""
 import json
 import os
@@ -14,7 +14,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (test infrastructure: lives under tests/)
 import refcases  # noqa: E402
 import sqlgen  # noqa: E402
 import tables as T  # noqa: E402
