@@ -164,6 +164,32 @@ def test_partition_tuple_widths(mixed):
     q.close()
 
 
+def test_wide_plans(mixed):
+    """many aggregates: 20+ state words per slot leave the LDS table only a few hundred
+    slots, so 1000 groups already take the partitioned path (wide tuples: 2 per thread
+    in aggregate, 1 per thread and chunk in refine), and the tile loop runs with fewer
+    unroll steps than the default (register budget)"""
+    import re
+    t, img, c = mixed
+    a, b, k, v, p, n = col("a"), col("b"), col("k"), col("v"), col("p"), col("n")
+    sel = [k, sum_(a), sum_(b), sum_(a * b), min_(a), max_(b), mean(v), sum_(v), count(1),
+           sum_(If(a > b, a - b, b - a)), max_(v * 2.0), min_(v), mean(a), mean(b), sum_(a % 7),
+           sum_(b % 13), min_(col("nb")), max_(p), sum_(n)]
+    for hint in (0, 1000, 3_000_000):
+        got, exp, st = check(t, img, select=sel, group_by=[k], where=(a > 100) & (b < 65000),
+                             groups_hint=hint)
+        assert st["num_groups"] == 1000
+    q = t.query(Plan(T.MIXED_SCHEMA, select=sel, group_by=[k], groups_hint=1000))
+    src = q.kernel_source()
+    q.close()
+    assert "evql_part_scatter" in src            # 1000 groups > the LDS slots of this plan
+    assert int(re.search(r"#define EVQL_UNROLL (\d+)", src).group(1)) < 4
+    assert int(re.search(r"#define EVQL_TUPLE_U32 (\d+)", src).group(1)) > 20
+    # the same select list over a two-column key with first-row values
+    check(t, img, key_cols=2, select=[k, col("f"), col("s")] + sel[1:], group_by=[k, col("f")],
+          groups_hint=5000)
+
+
 def test_global_aggregates(mixed):
     t, img, _ = mixed
     check(t, img, key_cols=0, select=[count(1)])
