@@ -122,7 +122,10 @@ def lib():
                                        C.c_uint64]
     L.evql_lsm_chain_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.evql_lsm_chain_destroy.argtypes = [C.c_void_p]
-    L.evql_lsm_chain_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _u8p, C.c_uint64]
+    L.evql_lsm_chain_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, _u8p, C.c_uint64]
+    L.evql_lsm_chain_length.argtypes = [C.c_void_p]
+    L.evql_query_create_chain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(K.PlanDesc),
+                                          C.POINTER(C.c_void_p)]
     L.evql_lsm_chain_build.argtypes = [C.c_void_p]
     L.evql_lsm_chain_filter.argtypes = [C.c_void_p, C.c_int, C.POINTER(_u8p), _u64p, _u64p]
     L.evql_merge_create.argtypes = [C.POINTER(K.PlanDesc), C.POINTER(C.c_void_p)]
@@ -464,9 +467,12 @@ class LsmChain:
         self.h = C.c_void_p()
         _check(lib().evql_lsm_chain_create(ctx.h, C.byref(self.h)))
 
-    def add(self, table, has_skip_column=False, arena_skiplist=None):
+    def add(self, table, has_skiplist=False, arena_skiplist=None, has_updates=True):
+        """tables in scan order (newest first); has_skiplist / has_updates are the file's
+        LSMTableRef flags, arena_skiplist (one byte per row) marks an arena"""
         sk = None if arena_skiplist is None else np.ascontiguousarray(arena_skiplist, np.uint8)
-        _check(lib().evql_lsm_chain_add(self.h, table.h, int(has_skip_column), _ptr(sk, _u8p),
+        flags = (K.LSM_HAS_SKIPLIST if has_skiplist else 0) | (K.LSM_HAS_UPDATES if has_updates else 0)
+        _check(lib().evql_lsm_chain_add(self.h, table.h, flags, _ptr(sk, _u8p),
                                         0 if sk is None else len(sk)))
         self.tables.append(table)
 
@@ -474,13 +480,22 @@ class LsmChain:
         _check(lib().evql_lsm_chain_build(self.h))
 
     def filter(self, idx):
-        """(bool array per row, rows kept) of the idx-th table"""
+        """(bool array per row -- None when the table needs no filter --, rows kept) of
+        the idx-th table"""
         bits = _u8p()
         n = C.c_uint64()
         kept = C.c_uint64()
         _check(lib().evql_lsm_chain_filter(self.h, idx, C.byref(bits), C.byref(n), C.byref(kept)))
+        if not bits:
+            return None, kept.value
         raw = np.frombuffer(C.string_at(bits, (n.value + 63) // 64 * 8), np.uint8)
         return np.unpackbits(raw, bitorder="little")[:n.value].astype(bool), kept.value
+
+    def query(self, plan):
+        """the operator over the whole chain (GroupByExpression over PartitionCursor)"""
+        q = C.c_void_p()
+        _check(lib().evql_query_create_chain(self.ctx.h, self.h, C.byref(plan.desc), C.byref(q)))
+        return Query(self, plan, q)
 
     def close(self):
         if self.h:

@@ -1,6 +1,8 @@
 /* gpu_group_by_scan.cc -- see gpu_group_by_scan.h */
 #include "gpu_group_by_scan.h"
+#include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <eventql/sql/qtree/GroupByNode.h>
 #include <eventql/sql/qtree/SequentialScanNode.h>
 #include <eventql/sql/runtime/QueryBuilder.h>
@@ -25,23 +27,62 @@ const char* statusCodeString(int rc) {
 }
 
 /* ---------------------------------------------------------------- registry */
-GpuTableRegistry::GpuTableRegistry(int device_ordinal)
-    : device_(device_ordinal), ctx_(nullptr), ctx_failed_(false) {}
+namespace {
+/* a partition's tables and row filters in HBM; released when the last operator over it
+ * and the registry have let go */
+struct ChainResident {
+  std::vector<std::shared_ptr<evql_table_t>> tables; /* scan order: newest first */
+  evql_lsm_chain_t* chain;
+  ChainResident() : chain(nullptr) {}
+  ~ChainResident() {
+    if (chain) evql_lsm_chain_destroy(chain);
+  }
+};
+}  // namespace
+
+GpuTableRegistry::GpuTableRegistry(int device_ordinal, uint64_t hbm_budget_bytes)
+    : device_(device_ordinal), budget_(hbm_budget_bytes), ctx_(nullptr), ctx_failed_(false),
+      clock_(0) {}
 
 GpuTableRegistry::~GpuTableRegistry() {
-  for (auto& t : tables_) {
-    if (t.second.table) evql_table_close(t.second.table);
-  }
+  tables_.clear(); /* chains before the files they hold, files before the context */
+  files_.clear();
   if (ctx_) evql_ctx_destroy(ctx_);
 }
 
 void GpuTableRegistry::registerTable(const std::string& table_name,
                                      const std::string& cstable_file, ScanKind kind,
                                      const std::string& version_tag) {
+  /* one immutable file: no skiplist, the oldest of its chain => PartitionCursor would
+   * not filter it either (partition_cursor.cc:149-151) */
+  registerChain(table_name, std::vector<ChainFile>{ChainFile{cstable_file, false, false}}, kind,
+                version_tag);
+}
+
+void GpuTableRegistry::registerChain(const std::string& table_name,
+                                     const std::vector<ChainFile>& oldest_first, ScanKind kind,
+                                     const std::string& version_tag) {
   std::unique_lock<std::mutex> lk(mutex_);
-  auto it = tables_.find(table_name);
-  if (it != tables_.end() && it->second.table) evql_table_close(it->second.table);
-  tables_[table_name] = Entry{cstable_file, kind, nullptr, version_tag};
+  ChainEntry e;
+  e.files = oldest_first;
+  e.kind = kind;
+  e.version_tag = version_tag;
+  tables_[table_name] = e; /* (a resident chain of the old registration is dropped) */
+}
+
+void GpuTableRegistry::unregisterTable(const std::string& table_name) {
+  std::unique_lock<std::mutex> lk(mutex_);
+  tables_.erase(table_name);
+}
+
+void GpuTableRegistry::setResolver(Resolver r) {
+  std::unique_lock<std::mutex> lk(mutex_);
+  resolver_ = r;
+}
+
+std::string GpuTableRegistry::lastError() {
+  std::unique_lock<std::mutex> lk(mutex_);
+  return last_error_;
 }
 
 evql_ctx_t* GpuTableRegistry::context() {
@@ -56,26 +97,169 @@ evql_ctx_t* GpuTableRegistry::context() {
   return ctx_;
 }
 
-evql_table_t* GpuTableRegistry::lookup(const std::string& table_name, ScanKind* kind,
-                                       std::string* version_tag) {
-  evql_ctx_t* ctx = context();
-  if (!ctx) return nullptr;
+uint64_t GpuTableRegistry::residentBytes() {
   std::unique_lock<std::mutex> lk(mutex_);
-  auto it = tables_.find(table_name);
-  if (it == tables_.end()) {
-    last_error_ = "table not registered with the GPU executor: " + table_name;
+  uint64_t b = 0;
+  for (const auto& f : files_) b += f.second.size;
+  return b;
+}
+
+/* (mutex held) the resident table of a file; re-read when the file changed on disk */
+std::shared_ptr<evql_table_t> GpuTableRegistry::openFile(const std::string& path,
+                                                         std::string* signature) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) {
+    last_error_ = "cannot stat " + path;
+    files_.erase(path);
     return nullptr;
   }
-  if (!it->second.table) {
-    if (evql_table_open_file(ctx, it->second.file.c_str(), &it->second.table) != EVQL_OK) {
+  const int64_t mtime_ns = (int64_t) st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+  char sig[96];
+  snprintf(sig, sizeof(sig), ":%llu:%lld;", (unsigned long long) st.st_size, (long long) mtime_ns);
+  *signature += path + sig;
+  auto it = files_.find(path);
+  if (it != files_.end() &&
+      (it->second.size != (uint64_t) st.st_size || it->second.mtime_ns != mtime_ns)) {
+    files_.erase(it); /* the file behind the name changed: the HBM copy is stale */
+    it = files_.end();
+  }
+  if (it == files_.end()) {
+    evql_table_t* t = nullptr;
+    if (evql_table_open_file(ctx_, path.c_str(), &t) != EVQL_OK) {
       last_error_ = evql_last_error();
-      it->second.table = nullptr;
       return nullptr;
     }
+    FileEntry fe;
+    fe.table = std::shared_ptr<evql_table_t>(t, evql_table_close);
+    fe.size = (uint64_t) st.st_size;
+    fe.mtime_ns = mtime_ns;
+    it = files_.insert(std::make_pair(path, fe)).first;
   }
-  if (kind) *kind = it->second.kind;
-  if (version_tag) *version_tag = it->second.version_tag;
+  it->second.last_use = ++clock_;
   return it->second.table;
+}
+
+/* (mutex held) least recently used files leave the registry until the budget holds; an
+ * operator that still runs over one keeps its own reference until it ends */
+void GpuTableRegistry::enforceBudget() {
+  for (;;) {
+    uint64_t total = 0;
+    for (const auto& f : files_) total += f.second.size;
+    if (total <= budget_ || files_.size() <= 1) return;
+    auto victim = files_.end();
+    for (auto it = files_.begin(); it != files_.end(); ++it) {
+      if (it->second.last_use == clock_) continue; /* the one just asked for */
+      if (victim == files_.end() || it->second.last_use < victim->second.last_use) victim = it;
+    }
+    if (victim == files_.end()) return;
+    /* chains built over the victim hold it too: drop those residents */
+    for (auto& t : tables_) {
+      for (const auto& cf : t.second.files) {
+        if (cf.file == victim->first) {
+          t.second.resident.reset();
+          t.second.signature.clear();
+        }
+      }
+    }
+    files_.erase(victim);
+  }
+}
+
+bool GpuTableRegistry::lookup(const std::string& table_name, ResidentSource* out) {
+  evql_ctx_t* ctx = context();
+  if (!ctx) return false;
+  std::unique_lock<std::mutex> lk(mutex_);
+  auto it = tables_.find(table_name);
+  ChainEntry resolved;
+  ChainEntry* e = nullptr;
+  if (it != tables_.end()) {
+    e = &it->second;
+  } else if (resolver_) {
+    Resolver r = resolver_;
+    lk.unlock(); /* (the resolver may take the server's own locks) */
+    const bool ok = r(table_name, &resolved.files, &resolved.kind, &resolved.version_tag);
+    lk.lock();
+    if (ok) {
+      /* remembered under the name so that the resident chain is reused while the
+       * resolver keeps giving the same files */
+      auto known = tables_.find("\001resolved:" + table_name);
+      if (known != tables_.end()) {
+        bool same = known->second.files.size() == resolved.files.size();
+        for (size_t i = 0; same && i < resolved.files.size(); ++i) {
+          same = known->second.files[i].file == resolved.files[i].file &&
+                 known->second.files[i].has_skiplist == resolved.files[i].has_skiplist &&
+                 known->second.files[i].has_updates == resolved.files[i].has_updates;
+        }
+        if (!same) known->second = resolved;
+        known->second.version_tag = resolved.version_tag;
+        known->second.kind = resolved.kind;
+        e = &known->second;
+      } else {
+        e = &(tables_["\001resolved:" + table_name] = resolved);
+      }
+    }
+  }
+  if (!e) {
+    last_error_ = "table not registered with the GPU executor: " + table_name;
+    return false;
+  }
+  if (e->files.empty()) {
+    last_error_ = "partition without LSM files: " + table_name;
+    return false;
+  }
+  /* files in scan order: newest first */
+  std::string signature;
+  std::vector<std::shared_ptr<evql_table_t>> tabs;
+  for (size_t i = e->files.size(); i-- > 0;) {
+    std::shared_ptr<evql_table_t> t = openFile(e->files[i].file, &signature);
+    if (!t) return false;
+    tabs.push_back(t);
+  }
+  out->kind = e->kind;
+  out->version_tag = e->version_tag;
+  out->table = nullptr;
+  out->chain = nullptr;
+  /* does any file get a row filter?  Not when no file has a skiplist and none but the
+   * oldest has updates (partition_cursor.cc:149-155 with an empty id set) */
+  bool filters = false;
+  for (size_t i = 0; i < e->files.size(); ++i) {
+    if (e->files[i].has_skiplist || (i > 0 && e->files[i].has_updates)) filters = true;
+  }
+  if (e->files.size() == 1 && !filters) {
+    out->table = tabs[0].get();
+    out->keepalive = tabs[0];
+    enforceBudget();
+    return true;
+  }
+  if (!e->resident || e->signature != signature) {
+    std::shared_ptr<ChainResident> cr(new ChainResident());
+    cr->tables = tabs;
+    if (evql_lsm_chain_create(ctx, &cr->chain) != EVQL_OK) {
+      last_error_ = evql_last_error();
+      return false;
+    }
+    for (size_t k = 0; k < tabs.size(); ++k) {
+      const ChainFile& cf = e->files[e->files.size() - 1 - k];
+      const uint32_t flags = (cf.has_skiplist ? EVQL_LSM_HAS_SKIPLIST : 0u) |
+                             (cf.has_updates ? EVQL_LSM_HAS_UPDATES : 0u);
+      if (evql_lsm_chain_add(cr->chain, tabs[k].get(), flags, nullptr, 0) != EVQL_OK) {
+        last_error_ = evql_last_error();
+        return false;
+      }
+    }
+    /* PartitionCursor::openNextTable's filter loops, all files at once, on the device */
+    if (evql_lsm_chain_build(cr->chain) != EVQL_OK) {
+      last_error_ = evql_last_error();
+      return false;
+    }
+    e->resident = cr;
+    e->signature = signature;
+  }
+  ChainResident* cr = static_cast<ChainResident*>(e->resident.get());
+  out->chain = cr->chain;
+  out->keepalive = e->resident;
+  enforceBudget();
+  return true;
 }
 
 /* ------------------------------------------------------------ plan lowering */
@@ -160,8 +344,10 @@ bool buildPlanDesc(csql::Transaction* txn, csql::GroupByNode* group,
 
 /* ----------------------------------------------------------------- operator */
 GpuGroupByScan::GpuGroupByScan(csql::Transaction* txn,
-                               csql::ExecutionContext* execution_context, evql_query_t* query)
-    : txn_(txn), execution_context_(execution_context), query_(query), completed_(false),
+                               csql::ExecutionContext* execution_context, evql_query_t* query,
+                               std::shared_ptr<void> source_keepalive)
+    : txn_(txn), execution_context_(execution_context), query_(query),
+      source_(source_keepalive), completed_(false),
       from_cache_(false), recording_(false), recorded_bytes_(0), replay_pos_(0) {
   execution_context_->incrementNumTasks(); /* groupby.cc:54 */
 }
@@ -335,18 +521,16 @@ csql::SType GpuGroupByScan::getColumnType(size_t idx) const {
 }
 
 /* ---------------------------------------------------------------- scheduler */
-GpuScheduler::GpuScheduler(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts)
+GpuLowering::GpuLowering(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts)
     : tables_(tables), opts_(opts), cache_hits_(new std::atomic<uint64_t>(0)) {}
 
-csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
-                                              csql::ExecutionContext* execution_context,
-                                              csql::GroupByNode* group,
-                                              csql::SequentialScanNode* seqscan,
-                                              std::string* why) {
-  ScanKind kind = ScanKind::FAST;
-  std::string version_tag;
-  evql_table_t* table = tables_->lookup(seqscan->tableName(), &kind, &version_tag);
-  if (!table) {
+csql::TableExpression* GpuLowering::tryLower(csql::Transaction* txn,
+                                             csql::ExecutionContext* execution_context,
+                                             csql::GroupByNode* group,
+                                             csql::SequentialScanNode* seqscan,
+                                             std::string* why) {
+  ResidentSource src;
+  if (!tables_->lookup(seqscan->tableName(), &src)) {
     *why = tables_->lastError();
     return nullptr;
   }
@@ -354,11 +538,14 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
   // a data node serving EVQL_OP_QUERY_PARTIALAGGR gets a GroupByNode marked partial
   // (server/sql/scheduler.cc:59-64): the operator then emits PartialGroupBy rows
   const bool partial = group != nullptr && (opts_.partial || group->isPartialAggregation());
-  if (!buildPlanDesc(txn, group, seqscan, kind, partial, &pb, why)) {
+  if (!buildPlanDesc(txn, group, seqscan, src.kind, partial, &pb, why)) {
     return nullptr;
   }
   evql_query_t* q = nullptr;
-  int rc = evql_query_create(tables_->context(), table, &pb.desc, &q);
+  // a partition's file chain: PartitionCursor under the GROUP BY (server/sql/
+  // partition_cursor.cc) -> one operator over all files, the row filters from the chain
+  int rc = src.chain ? evql_query_create_chain(tables_->context(), src.chain, &pb.desc, &q)
+                     : evql_query_create(tables_->context(), src.table, &pb.desc, &q);
   if (rc == EVQL_ENOTSUP) {
     *why = std::string("ENOTSUP: ") + evql_last_error();
     return nullptr;
@@ -368,7 +555,8 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
      * column type, CSTableScan.cc:783-784) */
     RAISE(kRuntimeError, evql_last_error());
   }
-  auto op = new GpuGroupByScan(txn, execution_context, q);
+  auto op = new GpuGroupByScan(txn, execution_context, q, src.keepalive);
+  const std::string& version_tag = src.version_tag;
   if (partial) op->markPartial();
   if (partial && !version_tag.empty()) {
     /* PartialGroupByExpression::getCacheKey = SHA1(input key + fingerprint of the
@@ -397,49 +585,39 @@ csql::TableExpression* GpuScheduler::tryLower(csql::Transaction* txn,
   return op;
 }
 
-ScopedPtr<csql::TableExpression> GpuScheduler::buildGroupByExpression(
-    csql::Transaction* txn, csql::ExecutionContext* execution_context,
-    RefPtr<csql::GroupByNode> node) {
-  if (opts_.lower_group_by) {
-    std::string why;
-    csql::TableExpression* op = nullptr;
-    auto seqscan = dynamic_cast<csql::SequentialScanNode*>(node->inputTable().get());
-    if (seqscan) {
-      op = tryLower(txn, execution_context, node.get(), seqscan, &why);
-    } else {
-      why = "input of the GROUP BY is not a sequential scan";
-    }
-    decisions_.push_back(Decision{"groupby", op != nullptr, why});
-    if (op) return ScopedPtr<csql::TableExpression>(op);
-    if (opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
+csql::TableExpression* GpuLowering::lowerGroupBy(csql::Transaction* txn,
+                                                 csql::ExecutionContext* execution_context,
+                                                 csql::GroupByNode* node) {
+  std::string why;
+  csql::TableExpression* op = nullptr;
+  auto seqscan = dynamic_cast<csql::SequentialScanNode*>(node->inputTable().get());
+  if (seqscan) {
+    op = tryLower(txn, execution_context, node, seqscan, &why);
+  } else {
+    why = "input of the GROUP BY is not a sequential scan";
   }
-  return csql::DefaultScheduler::buildGroupByExpression(txn, execution_context, node);
+  decisions_.push_back(Decision{"groupby", op != nullptr, why});
+  if (!op && opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
+  return op;
 }
 
-ScopedPtr<csql::TableExpression> GpuScheduler::buildSequentialScan(
-    csql::Transaction* txn, csql::ExecutionContext* execution_context,
-    RefPtr<csql::SequentialScanNode> node) {
-  if (opts_.lower_scans) {
-    std::string why;
-    csql::TableExpression* op = tryLower(txn, execution_context, nullptr, node.get(), &why);
-    decisions_.push_back(Decision{"seqscan", op != nullptr, why});
-    if (op) return ScopedPtr<csql::TableExpression>(op);
-    if (opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
-  }
-  return csql::DefaultScheduler::buildSequentialScan(txn, execution_context, node);
+csql::TableExpression* GpuLowering::lowerScan(csql::Transaction* txn,
+                                              csql::ExecutionContext* execution_context,
+                                              csql::SequentialScanNode* node) {
+  std::string why;
+  csql::TableExpression* op = tryLower(txn, execution_context, nullptr, node, &why);
+  decisions_.push_back(Decision{"seqscan", op != nullptr, why});
+  if (!op && opts_.strict) RAISEF(kRuntimeError, "GPU executor: not lowered: $0", why);
+  return op;
 }
 
 /* ORDER BY / LIMIT directly above a lowered GROUP BY: into the operator (its top-k runs
  * on the device over the dense group records); anything else: the reference's operators
  * stacked on the input that was just built (scheduler.cc:36-49, 95-132) */
-ScopedPtr<csql::TableExpression> GpuScheduler::buildOrderByExpression(
-    csql::Transaction* txn, csql::ExecutionContext* execution_context,
-    RefPtr<csql::OrderByNode> node) {
-  if (!opts_.lower_group_by || !opts_.fuse_order_by) {
-    return csql::DefaultScheduler::buildOrderByExpression(txn, execution_context, node);
-  }
-  auto input = buildTableExpression(
-      txn, execution_context, node->inputTable().asInstanceOf<csql::TableExpressionNode>());
+ScopedPtr<csql::TableExpression> GpuLowering::orderBy(csql::Transaction* txn,
+                                                      csql::ExecutionContext* execution_context,
+                                                      csql::OrderByNode* node,
+                                                      ScopedPtr<csql::TableExpression> input) {
   std::string why = "input is not the GPU operator";
   auto gpu = dynamic_cast<GpuGroupByScan*>(input.get());
   const bool fused = gpu && gpu->setOrder(node->sortSpecs(), &why);
@@ -462,14 +640,9 @@ ScopedPtr<csql::TableExpression> GpuScheduler::buildOrderByExpression(
                                               comparators, std::move(input)));
 }
 
-ScopedPtr<csql::TableExpression> GpuScheduler::buildLimit(
-    csql::Transaction* txn, csql::ExecutionContext* execution_context,
-    RefPtr<csql::LimitNode> node) {
-  if (!opts_.lower_group_by || !opts_.fuse_order_by) {
-    return csql::DefaultScheduler::buildLimit(txn, execution_context, node);
-  }
-  auto input = buildTableExpression(
-      txn, execution_context, node->inputTable().asInstanceOf<csql::TableExpressionNode>());
+ScopedPtr<csql::TableExpression> GpuLowering::limit(csql::ExecutionContext* execution_context,
+                                                    csql::LimitNode* node,
+                                                    ScopedPtr<csql::TableExpression> input) {
   std::string why = "input is not the GPU operator";
   auto gpu = dynamic_cast<GpuGroupByScan*>(input.get());
   const bool fused = gpu && gpu->setLimit(node->limit(), node->offset(), &why);

@@ -7,7 +7,13 @@
  * sql/statements/select/groupby.h; it is installed exactly like
  * eventql::Scheduler (server/sql/scheduler.cc:55-77):
  *
- *     runtime->setScheduler(mkScoped(new evql_adapter::GpuScheduler(opts)));
+ *     runtime->setScheduler(mkScoped(
+ *         new evql_adapter::GpuSchedulerT<eventql::Scheduler>(tables, opts, config, pmap, cdir, auth)));
+ *
+ * GpuSchedulerT<Base> is a mix-in over any csql::DefaultScheduler subclass: it tries the
+ * GPU operator first and delegates everything it does not lower to Base -- over
+ * eventql::Scheduler (server/sql/scheduler.h:37) that is the partition fan-out
+ * (buildPipelineGroupByExpression) and the CPU PartialGroupByExpression.
  *
  *   csql::TableExpression               sql/table_expression.h:35-50
  *   csql::DefaultScheduler              sql/scheduler.h:78-173 (virtual build*)
@@ -17,6 +23,7 @@
  */
 #pragma once
 #include <atomic>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -40,16 +47,38 @@ enum class ScanKind {
   DREMEL  /* CSTableScan     (partition_cursor.cc:206-213)                          */
 };
 
+/* one LSM file of a partition (db/partition_state.proto LSMTableRef) */
+struct ChainFile {
+  std::string file;   /* <base_path>/<filename>.cst */
+  bool has_skiplist;  /* LSMTableRef::has_skiplist */
+  bool has_updates;   /* LSMTableRef::has_updates  */
+};
+
+/* what a lowered operator scans; keeps the HBM-resident tables alive while it runs */
+struct ResidentSource {
+  evql_table_t* table = nullptr;      /* a single file without row filter, or      */
+  evql_lsm_chain_t* chain = nullptr;  /* the file chain of a partition, filters built */
+  ScanKind kind = ScanKind::FAST;
+  std::string version_tag;
+  std::shared_ptr<void> keepalive;
+};
+
 /*
  * cstable files resident in HBM, keyed by SQL table name.  The reference's
  * TableProvider hides the file name (CSTableScanProvider::cstable_file_ is
- * protected), so whoever registers the provider registers the file here too; in
- * evqld the equivalent call sits in PartitionCursor::openNextTable
- * (server/sql/partition_cursor.cc:197-213), where the file name is at hand.
+ * protected), so whoever registers the provider registers the file here too; for
+ * evqld's partitions (server/sql/table_scan.cc:116-144 -> PartitionCursor) a resolver
+ * maps the scan's table name ("tsdb://localhost/<table>/<partition>") to the
+ * partition's file chain -- gpu_partition.h builds one from a PartitionSnapshot.
+ *
+ * Files are opened once and stay in HBM across queries.  Every lookup stats the file:
+ * when size or mtime changed the resident copy is dropped and the file is read again.
+ * Resident bytes are bounded by a budget (least recently used files go first; a table
+ * still in use by a running operator is released when that operator ends).
  */
 class GpuTableRegistry {
 public:
-  explicit GpuTableRegistry(int device_ordinal = 0);
+  explicit GpuTableRegistry(int device_ordinal = 0, uint64_t hbm_budget_bytes = 200ull << 30);
   ~GpuTableRegistry();
   GpuTableRegistry(const GpuTableRegistry&) = delete;
 
@@ -59,25 +88,53 @@ public:
   void registerTable(const std::string& table_name, const std::string& cstable_file,
                      ScanKind kind = ScanKind::FAST, const std::string& version_tag = "");
 
-  /* opens (once) and returns the resident table; nullptr when the name is unknown
-   * or no device is present -- the caller then keeps the CPU operators */
-  evql_table_t* lookup(const std::string& table_name, ScanKind* kind,
-                       std::string* version_tag = nullptr);
+  /* a partition: its LSM files OLDEST first, as PartitionState::lsm_tables lists them
+   * (PartitionCursor walks them backwards, partition_cursor.cc:134-143) */
+  void registerChain(const std::string& table_name, const std::vector<ChainFile>& oldest_first,
+                     ScanKind kind = ScanKind::FAST, const std::string& version_tag = "");
+  void unregisterTable(const std::string& table_name);
+
+  /* asked for names nobody registered; false => not a GPU table (CPU operators).
+   * Called on every lookup of such a name: the answer follows the partition's
+   * current snapshot. */
+  typedef std::function<bool(const std::string& table_name, std::vector<ChainFile>* oldest_first,
+                             ScanKind* kind, std::string* version_tag)> Resolver;
+  void setResolver(Resolver r);
+
+  /* false when the name is unknown, a file cannot be opened or no device is present
+   * (lastError() says which) -- the caller then keeps the CPU operators */
+  bool lookup(const std::string& table_name, ResidentSource* out);
   evql_ctx_t* context();
-  const std::string& lastError() const { return last_error_; }
+  std::string lastError();
+  uint64_t residentBytes();
 
 private:
-  struct Entry {
-    std::string file;
-    ScanKind kind;
-    evql_table_t* table;
-    std::string version_tag;
+  struct FileEntry {
+    std::shared_ptr<evql_table_t> table;
+    uint64_t size = 0;
+    int64_t mtime_ns = 0;
+    uint64_t last_use = 0;
   };
+  struct ChainEntry {
+    std::vector<ChainFile> files; /* oldest first */
+    ScanKind kind = ScanKind::FAST;
+    std::string version_tag;
+    /* built filters, valid while the files' identities are unchanged */
+    std::shared_ptr<void> resident; /* ChainResident */
+    std::string signature;
+  };
+  std::shared_ptr<evql_table_t> openFile(const std::string& path, std::string* signature);
+  void enforceBudget();
+
   std::mutex mutex_;
   int device_;
+  uint64_t budget_;
   evql_ctx_t* ctx_;
   bool ctx_failed_;
-  std::map<std::string, Entry> tables_;
+  uint64_t clock_;
+  std::map<std::string, ChainEntry> tables_;
+  std::map<std::string, FileEntry> files_;
+  Resolver resolver_;
   std::string last_error_;
 };
 
@@ -104,7 +161,7 @@ public:
   static const size_t kOutputBatchSize = 1024; /* groupby.h:36, CSTableScan.h:46 */
 
   GpuGroupByScan(csql::Transaction* txn, csql::ExecutionContext* execution_context,
-                 evql_query_t* query);
+                 evql_query_t* query, std::shared_ptr<void> source_keepalive = nullptr);
   ~GpuGroupByScan() override;
 
   ReturnCode execute() override;
@@ -136,6 +193,7 @@ private:
   csql::Transaction* txn_;
   csql::ExecutionContext* execution_context_;
   evql_query_t* query_;
+  std::shared_ptr<void> source_; /* the tables / filter chain the query reads */
   bool completed_;
   bool partial_ = false;
   Option<SHA1Hash> cache_key_;
@@ -159,48 +217,115 @@ struct GpuSchedulerOptions {
   bool strict;         /* tests: RAISE instead of falling back to the CPU operators */
 };
 
-class GpuScheduler : public csql::DefaultScheduler {
+/* the part of the scheduler hook that does not depend on the base scheduler */
+class GpuLowering {
 public:
-  GpuScheduler(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts);
+  GpuLowering(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts);
 
-  /* diagnostics: how the last build* calls were answered */
   struct Decision {
-    std::string node;     /* "groupby" | "seqscan" */
+    std::string node;     /* "groupby" | "seqscan" | "orderby" | "limit" */
     bool lowered;
     std::string reason;   /* why not, when !lowered */
   };
-  const std::vector<Decision>& decisions() const { return decisions_; }
-  void clearDecisions() { decisions_.clear(); }
-  uint64_t queryCacheHits() const { return cache_hits_->load(); }
 
-protected:
-  ScopedPtr<csql::TableExpression> buildGroupByExpression(
-      csql::Transaction* txn, csql::ExecutionContext* execution_context,
-      RefPtr<csql::GroupByNode> node) override;
-
-  ScopedPtr<csql::TableExpression> buildSequentialScan(
-      csql::Transaction* txn, csql::ExecutionContext* execution_context,
-      RefPtr<csql::SequentialScanNode> node) override;
-
-  ScopedPtr<csql::TableExpression> buildOrderByExpression(
-      csql::Transaction* txn, csql::ExecutionContext* execution_context,
-      RefPtr<csql::OrderByNode> node) override;
-
-  ScopedPtr<csql::TableExpression> buildLimit(
-      csql::Transaction* txn, csql::ExecutionContext* execution_context,
-      RefPtr<csql::LimitNode> node) override;
-
-  /* nullptr => keep the CPU operators */
+  /* nullptr => keep the CPU operators (*why says why) */
   csql::TableExpression* tryLower(csql::Transaction* txn,
                                   csql::ExecutionContext* execution_context,
                                   csql::GroupByNode* group, csql::SequentialScanNode* seqscan,
                                   std::string* why);
+  /* GROUP BY node -> operator, or nullptr; records the decision; RAISEs in strict mode */
+  csql::TableExpression* lowerGroupBy(csql::Transaction* txn, csql::ExecutionContext* ctx,
+                                      csql::GroupByNode* node);
+  csql::TableExpression* lowerScan(csql::Transaction* txn, csql::ExecutionContext* ctx,
+                                   csql::SequentialScanNode* node);
+  /* ORDER BY / LIMIT above an operator that was just built: fused into it when it is the
+   * GPU operator, the reference's CPU operator stacked on it otherwise
+   * (sql/scheduler.cc:36-49, 95-132) */
+  ScopedPtr<csql::TableExpression> orderBy(csql::Transaction* txn, csql::ExecutionContext* ctx,
+                                           csql::OrderByNode* node,
+                                           ScopedPtr<csql::TableExpression> input);
+  ScopedPtr<csql::TableExpression> limit(csql::ExecutionContext* ctx, csql::LimitNode* node,
+                                         ScopedPtr<csql::TableExpression> input);
 
   std::shared_ptr<GpuTableRegistry> tables_;
   GpuSchedulerOptions opts_;
   std::vector<Decision> decisions_;
   std::shared_ptr<std::atomic<uint64_t>> cache_hits_;
 };
+
+/*
+ * The scheduler hook as a mix-in over any csql::DefaultScheduler subclass.
+ *   GpuSchedulerT<csql::DefaultScheduler>   standalone csql (tests, the probe)
+ *   GpuSchedulerT<eventql::Scheduler>       evqld: the object handed to
+ *                                           Runtime::setScheduler INSTEAD of
+ *                                           eventql::Scheduler; what is not lowered
+ *                                           reaches eventql::Scheduler's overrides
+ *                                           unchanged (server/sql/scheduler.cc:55-162)
+ * Base's constructor arguments follow (tables, opts).
+ */
+template <class Base>
+class GpuSchedulerT : public Base {
+public:
+  template <class... BaseArgs>
+  GpuSchedulerT(std::shared_ptr<GpuTableRegistry> tables, GpuSchedulerOptions opts,
+                BaseArgs&&... base_args)
+      : Base(std::forward<BaseArgs>(base_args)...), gpu_(tables, opts) {}
+
+  /* diagnostics: how the last build* calls were answered */
+  typedef GpuLowering::Decision Decision;
+  const std::vector<Decision>& decisions() const { return gpu_.decisions_; }
+  void clearDecisions() { gpu_.decisions_.clear(); }
+  uint64_t queryCacheHits() const { return gpu_.cache_hits_->load(); }
+
+protected:
+  ScopedPtr<csql::TableExpression> buildGroupByExpression(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::GroupByNode> node) override {
+    if (gpu_.opts_.lower_group_by) {
+      csql::TableExpression* op = gpu_.lowerGroupBy(txn, execution_context, node.get());
+      if (op) return ScopedPtr<csql::TableExpression>(op);
+    }
+    return Base::buildGroupByExpression(txn, execution_context, node);
+  }
+
+  ScopedPtr<csql::TableExpression> buildSequentialScan(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::SequentialScanNode> node) override {
+    if (gpu_.opts_.lower_scans) {
+      csql::TableExpression* op = gpu_.lowerScan(txn, execution_context, node.get());
+      if (op) return ScopedPtr<csql::TableExpression>(op);
+    }
+    return Base::buildSequentialScan(txn, execution_context, node);
+  }
+
+  ScopedPtr<csql::TableExpression> buildOrderByExpression(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::OrderByNode> node) override {
+    if (!gpu_.opts_.lower_group_by || !gpu_.opts_.fuse_order_by) {
+      return Base::buildOrderByExpression(txn, execution_context, node);
+    }
+    return gpu_.orderBy(txn, execution_context, node.get(),
+                        this->buildTableExpression(
+                            txn, execution_context,
+                            node->inputTable().template asInstanceOf<csql::TableExpressionNode>()));
+  }
+
+  ScopedPtr<csql::TableExpression> buildLimit(
+      csql::Transaction* txn, csql::ExecutionContext* execution_context,
+      RefPtr<csql::LimitNode> node) override {
+    if (!gpu_.opts_.lower_group_by || !gpu_.opts_.fuse_order_by) {
+      return Base::buildLimit(txn, execution_context, node);
+    }
+    return gpu_.limit(execution_context, node.get(),
+                      this->buildTableExpression(
+                          txn, execution_context,
+                          node->inputTable().template asInstanceOf<csql::TableExpressionNode>()));
+  }
+
+  GpuLowering gpu_;
+};
+
+typedef GpuSchedulerT<csql::DefaultScheduler> GpuScheduler;
 
 const char* statusCodeString(int evql_status_code);
 

@@ -183,6 +183,7 @@ class ExchangeStats(C.Structure):
 
 EXCHANGE_GATHER_ALL = 0
 EXCHANGE_BY_OWNER = 1
+LSM_HAS_SKIPLIST, LSM_HAS_UPDATES = 1, 2
 
 # evql_transport_t callbacks
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64,

@@ -1076,6 +1076,10 @@ __global__ void __launch_bounds__(kBlock) k_lsm_insert(LsmArgs a) {
       continue;
     }
     if (skip || !upd) continue;
+    // (the id set is no longer empty: what the next table's "needs a filter" test reads)
+    if (__hip_atomic_load(&a.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      atomicOr((unsigned long long*) &a.counters[2], 1ull);
+    }
     u64 h = evql_mix64(id[0] ^ evql_mix64(id[1] + id[2])) & mask;
     for (u64 probe = 0; probe < a.cap; ++probe, h = (h + 1) & mask) {
       u64 prev = atomicCAS((unsigned long long*) &a.tab[h], EVQL_EMPTY, id[0]);

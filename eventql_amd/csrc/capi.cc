@@ -19,6 +19,10 @@ Status query_finish(evql_query* q);
 Status query_reset(evql_query* q);
 Status query_recount(evql_query* q);
 Status query_dense_into_table(evql_query* q);
+Status chain_merge(evql_query* head);  // exchange.cc
+size_t lsm_chain_parts(const evql_lsm_chain* ch, std::vector<evql_table*>* tables,
+                       std::vector<const uint8_t*>* d_filters);  // lsm.cc
+evql_ctx* lsm_chain_ctx(const evql_lsm_chain* ch);
 Status query_reserve_groups(evql_query* q, uint64_t extra);
 Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n, int64_t limit,
                        uint64_t offset);
@@ -518,10 +522,12 @@ int evql_writer_write_file(const evql_writer_t* w, const char* path) {
 void evql_writer_destroy(evql_writer_t* w) { delete w; }
 
 // ---- queries --------------------------------------------------------------------------
-int evql_query_create(evql_ctx_t* ctx, evql_table_t* table, const evql_plan_desc_t* plan,
-                      evql_query_t** out) {
-  API_TRY
-  if (hipSetDevice(ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
+// one operator over one table.  d_filter != nullptr: a row filter that already sits in HBM
+// (an evql_lsm_chain's; borrowed) instead of plan->row_filter_bits
+static int create_one(evql_ctx_t* ctx, evql_table_t* table, const evql_plan_desc_t* plan_in,
+                      const uint8_t* d_filter, evql_query_t** out) {
+  evql_plan_desc_t plan_copy = *plan_in;
+  const evql_plan_desc_t* plan = &plan_copy;
   std::unique_ptr<evql_query> q(new evql_query());
   q->ctx = ctx;
   q->table = table;
@@ -537,7 +543,14 @@ int evql_query_create(evql_ctx_t* ctx, evql_table_t* table, const evql_plan_desc
   if (plan->group_mode != EVQL_MODE_FINAL && plan->group_mode != EVQL_MODE_PARTIAL) {
     return fail(EVQL_EARG, "bad group mode");
   }
-  if (plan->row_filter_bits) {
+  if (d_filter) {
+    static const uint8_t marker = 0;  // (the planner only asks whether there is a filter)
+    plan_copy.row_filter_bits = &marker;
+    plan_copy.row_filter_len = table->layout.num_rows;
+    q->row_filter_len = table->layout.num_rows;
+    q->d_row_filter = const_cast<uint8_t*>(d_filter);
+    q->row_filter_owned = false;
+  } else if (plan->row_filter_bits) {
     q->row_filter_len = plan->row_filter_len;
     q->row_filter_host.assign(plan->row_filter_bits,
                               plan->row_filter_bits + (plan->row_filter_len + 7) / 8);
@@ -549,27 +562,97 @@ int evql_query_create(evql_ctx_t* ctx, evql_table_t* table, const evql_plan_desc
   if (!st.ok()) return ret(st);
   *out = q.release();
   return EVQL_OK;
+}
+
+int evql_query_create(evql_ctx_t* ctx, evql_table_t* table, const evql_plan_desc_t* plan,
+                      evql_query_t** out) {
+  API_TRY
+  if (!ctx || !table || !plan || !out) return fail(EVQL_EARG, "null argument");
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
+  return create_one(ctx, table, plan, nullptr, out);
+  API_CATCH
+}
+
+int evql_query_create_chain(evql_ctx_t* ctx, evql_lsm_chain_t* ch, const evql_plan_desc_t* plan,
+                            evql_query_t** out) {
+  API_TRY
+  if (!ctx || !ch || !plan || !out) return fail(EVQL_EARG, "null argument");
+  if (lsm_chain_ctx(ch) != ctx) return fail(EVQL_EARG, "chain belongs to another context");
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(EVQL_EDEVICE, "hipSetDevice failed");
+  std::vector<evql_table*> tables;
+  std::vector<const uint8_t*> d_filters;
+  if (lsm_chain_parts(ch, &tables, &d_filters) == 0) return fail(EVQL_EARG, "chain was not built");
+  if (plan->row_filter_bits || plan->row_begin || plan->row_end) {
+    return fail(EVQL_EARG, "a chain scan takes its row filters from the chain");
+  }
+  if (tables.size() > 1 && plan->scan_mode != EVQL_SCAN_FLAT) {
+    // PartitionCursor builds CSTableScan for aggregating statements (partition_cursor.cc:
+    // 205-213); its setFilter is not lowered
+    return fail(EVQL_ENOTSUP, "nested scan over a chain of tables");
+  }
+  if (tables.size() > 1 && plan->n_select == 0 && plan->n_group == 0) {
+    return fail(EVQL_ENOTSUP, "bare scan over a chain of tables");
+  }
+  std::vector<std::unique_ptr<evql_query>> parts;
+  for (size_t i = 0; i < tables.size(); ++i) {
+    // a table without a filter is created as a plain scan (setFilter is not called)
+    evql_query* q = nullptr;
+    int rc = create_one(ctx, tables[i], plan, d_filters[i], &q);
+    if (rc != EVQL_OK) return rc;
+    parts.emplace_back(q);
+  }
+  evql_query* head = parts[0].get();
+  // exact float sums: one quantum for the whole chain (the words of the parts are added)
+  for (int k = 0; k < 4; ++k) {
+    int ex = head->fsum_exp[k];
+    double b = head->fsum_bound[k];
+    for (auto& p : parts) {
+      ex = std::max(ex, p->fsum_exp[k]);
+      b = std::max(b, p->fsum_bound[k]);
+    }
+    for (auto& p : parts) {
+      p->fsum_exp[k] = ex;
+      p->fsum_bound[k] = b;
+    }
+  }
+  for (size_t i = 1; i < parts.size(); ++i) head->chain.push_back(parts[i].release());
+  *out = parts[0].release();
+  return EVQL_OK;
   API_CATCH
 }
 
 void evql_query_destroy(evql_query_t* q) { delete q; }
 
+// a chain query runs the scans of all its tables (head first), then merges their groups
+static Status launch_all(evql_query* q) {
+  Status st = query_launch(q);
+  for (size_t i = 0; st.ok() && i < q->chain.size(); ++i) st = query_launch(q->chain[i]);
+  return st;
+}
+
+static Status finish_all(evql_query* q) {
+  Status st = query_finish(q);
+  for (size_t i = 0; st.ok() && i < q->chain.size(); ++i) st = query_finish(q->chain[i]);
+  if (st.ok() && !q->chain.empty()) st = chain_merge(q);
+  return st;
+}
+
 int evql_query_launch(evql_query_t* q) {
   API_TRY
-  return ret(query_launch(q));
+  return ret(launch_all(q));
   API_CATCH
 }
 
 int evql_query_finish(evql_query_t* q) {
   API_TRY
-  return ret(query_finish(q));
+  return ret(finish_all(q));
   API_CATCH
 }
 
 int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user) {
   API_TRY
   if (hb && hb(user) != 0) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
-  Status st = query_launch(q);
+  Status st = launch_all(q);
   if (!st.ok()) return ret(st);
   // GroupByExpression::execute calls txn_->triggerHeartbeat() once per input batch
   // (groupby.cc:100-105) so that a long scan keeps its connection alive; here the scan
@@ -588,7 +671,7 @@ int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user) {
       }
     }
   }
-  st = query_finish(q);
+  st = finish_all(q);
   if (!st.ok()) return ret(st);
   if (aborted || (hb && hb(user) != 0)) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
   return EVQL_OK;
@@ -621,8 +704,11 @@ int evql_query_stats(const evql_query_t* q, evql_query_stats_t* out) {
   }
   // scaled to the scanned row range; + result bytes (key + 8 B per aggregate)
   const uint64_t nrows = q->table->layout.num_rows;
-  if (nrows && q->stats.rows_scanned != nrows) {
+  if (nrows && q->stats.rows_scanned != nrows && q->chain.empty()) {
     bytes = uint64_t(double(bytes) * double(q->stats.rows_scanned) / double(nrows));
+  }
+  for (const evql_query* part : q->chain) {  // (chain_merge summed the row counters)
+    for (const auto& c : part->kp.cols) bytes += part->table->payload_bytes[c.layout_index];
   }
   bytes += q->stats.num_groups * 8 * (1 + q->kp.aggs.size());
   out->algorithmic_bytes = bytes;
@@ -637,6 +723,8 @@ uint32_t evql_query_record_words(const evql_query_t* q) {
 }
 
 int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out) {
+  if (!q || !out) return fail(EVQL_EARG, "null argument");
+  if (q->merged) return fail(EVQL_EARG, "the query's groups were merged (exchange / chain): emit them with next_batch");
   {
     Status st = query_dense_into_table(q);
     if (!st.ok()) return ret(st);
@@ -651,6 +739,12 @@ int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out) {
 int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_groups,
                              uint64_t* n_groups) {
   API_TRY
+  if (q->merged) return fail(EVQL_EARG, "the query's groups were merged (exchange / chain): emit them with next_batch");
+  if (q->kp.n_exact > 0 && !(q->float_sum_bound > 0)) {
+    // the records carry integer multiples of a quantum derived from ONE table's maxima;
+    // another partition may have chosen a different one
+    return fail(EVQL_EARG, "exact float sums travel between partitions only with an explicit float_sum_bound");
+  }
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   if (q->kp.need_first_row) {
     // a first-row index means something only inside the table that produced it:
@@ -685,6 +779,12 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
 
 int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n_groups) {
   API_TRY
+  if (q->merged) return fail(EVQL_EARG, "the query's groups were merged (exchange / chain): emit them with next_batch");
+  if (q->kp.n_exact > 0 && !(q->float_sum_bound > 0)) {
+    // the records carry integer multiples of a quantum derived from ONE table's maxima;
+    // another partition may have chosen a different one
+    return fail(EVQL_EARG, "exact float sums travel between partitions only with an explicit float_sum_bound");
+  }
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   if (q->kp.need_first_row) {
     return fail(EVQL_ENOTSUP, "plan reads first-row values: merge it with evql_query_exchange");

@@ -285,8 +285,31 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   const bool resolved = kp.need_first_row;
   const uint32_t rw_in = W + 1;
   const uint32_t rw = resolved ? rw_in + nc + 1 : rw_in;  // wire record words
+  // (checked before anything is allocated or filled: the merged slot is W + nc + 1 words)
+  if ((resolved ? W + nc + 1 : W) > uint32_t(kMaxStateWords + 3)) {
+    return Status::error(EVQL_ENOTSUP, "too many words per merged group");
+  }
   auto t0 = std::chrono::steady_clock::now();
   x->stats = evql_exchange_stats_t{};
+  if (kp.n_exact > 0) {
+    // EVQL_FLOAT_SUM_EXACT: the state words are integer multiples of 2^fsum_exp and are
+    // added as they are -- every rank must have chosen the same quantum.  With
+    // float_sum_bound = 0 each rank derives it from its OWN table's maxima, which may
+    // fall on either side of a power of two.
+    std::vector<uint64_t> mine_e(4), all_e(uint64_t(4) * N);
+    for (int k = 0; k < 4; ++k) mine_e[k] = uint64_t(int64_t(q->fsum_exp[k]));
+    int rce = x->tr.all_gather_u64(x->tr.user, mine_e.data(), 4, all_e.data());
+    if (rce != EVQL_OK) return Status::error(rce, "exchange: all_gather of the sum quanta failed");
+    for (int r = 0; r < N; ++r) {
+      for (int k = 0; k < kp.n_exact; ++k) {
+        if (all_e[uint64_t(r) * 4 + k] != mine_e[k]) {
+          return Status::error(EVQL_EARG,
+                               "exact float sums: the ranks chose different quanta (the tables' "
+                               "maxima differ); pass the same float_sum_bound on every rank");
+        }
+      }
+    }
+  }
 
   // ---- 1. this rank's groups as dense records ---------------------------------------------
   const uint64_t n = q->ngroups;
@@ -533,7 +556,6 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
                                      0xFFF0000000000000ull};
   for (const auto& sw : kp.states) ia.identity[w++] = kIdent[sw.op & 7];
   for (; w < int(mw); ++w) ia.identity[w] = 0;
-  if (mw > kMaxStateWords + 3) return Status::error(EVQL_ENOTSUP, "too many words per merged group");
   HIP_TRY(launch_table_init(ia, s));
   MergeResolvedArgs ma{};
   ma.m.words = q->d_mtab;
@@ -601,6 +623,282 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
 }
 
 }  // namespace
+
+// -----------------------------------------------------------------------------------------
+// chains: the tables of one partition scanned by one operator each (evql_query_create_chain)
+// -----------------------------------------------------------------------------------------
+// PartitionCursor hands the batches of its scans to ONE GroupByExpression, newest table
+// first (server/sql/partition_cursor.cc:56-81, groupby.cc:69-185).  Here every table was
+// aggregated by its own launch; their groups are merged like the partial aggregates of
+// several ranks -- table i plays rank i: records in chain order into a fresh table, first
+// rows resolved inside the table that produced them, (table << 44 | row) as the scan
+// position, string bytes into one heap, count_distinct pairs re-inserted into one set.
+namespace evql {
+
+Status chain_merge(evql_query* head) {
+  evql_ctx* ctx = head->ctx;
+  hipStream_t s = ctx->stream;
+  const KernelPlan& kp = head->kp;
+  std::vector<evql_query*> parts;
+  parts.push_back(head);
+  for (evql_query* c : head->chain) parts.push_back(c);
+  const uint32_t W = uint32_t(kp.words_per_slot());
+  const uint32_t nc = uint32_t(kp.cols.size());
+  const bool resolved = kp.need_first_row;
+  const uint32_t rw_in = W + 1;
+  const uint32_t rw = resolved ? rw_in + nc + 1 : rw_in;
+  const uint32_t mw = resolved ? W + nc + 1 : W;
+  if (mw > uint32_t(kMaxStateWords + 3)) {
+    return Status::error(EVQL_ENOTSUP, "too many words per merged group");
+  }
+  if (parts.size() >= (1u << 19)) return Status::error(EVQL_EARG, "too many tables in a chain");
+  uint64_t total = 0, max_n = 0;
+  for (evql_query* p : parts) {
+    // (same plan everywhere: the slot layouts agree; a different KEY mode or word count
+    // would mean different plans)
+    if (uint32_t(p->kp.words_per_slot()) != W || p->kp.cols.size() != nc ||
+        p->kp.key_mode != kp.key_mode || p->kp.need_first_row != kp.need_first_row) {
+      return Status::error(EVQL_ERUNTIME, "chain: the tables' plans disagree");
+    }
+    if (!p->executed) return Status::error(EVQL_EARG, "execute() was not called");
+    total += p->ngroups;
+    max_n = std::max(max_n, p->ngroups);
+  }
+  // ---- the merged table ---------------------------------------------------------------------
+  uint64_t cap = 1 << 16;
+  while (cap < total * 2) cap <<= 1;
+  if (!head->d_mtab || head->mcap != cap || head->m_words != mw) {
+    if (head->d_mtab) hipFree(head->d_mtab);
+    head->d_mtab = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&head->d_mtab), (cap + 8) * uint64_t(mw) * 8));
+  }
+  head->mcap = cap;
+  head->m_words = mw;
+  TableInitArgs ia{};
+  ia.words = head->d_mtab;
+  ia.stride = cap + 8;
+  ia.nwords = mw;
+  ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
+  int w = 1;
+  if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+  static const uint64_t kIdent[8] = {0, 0, 0xFFFFFFFFFFFFFFFFull, 0, 0x7FFFFFFFFFFFFFFFull,
+                                     0x8000000000000000ull, 0x7FF0000000000000ull,
+                                     0xFFF0000000000000ull};
+  for (const auto& sw : kp.states) ia.identity[w++] = kIdent[sw.op & 7];
+  for (; w < int(mw); ++w) ia.identity[w] = 0;
+  HIP_TRY(launch_table_init(ia, s));
+  MergeResolvedArgs ma{};
+  ma.m.words = head->d_mtab;
+  ma.m.gcap = cap;
+  ma.m.stride = cap + 8;
+  ma.m.nwords = mw;
+  ma.m.has_ident2 = kp.has_ident2() ? 1 : 0;
+  w = 1;
+  if (kp.has_ident2()) ma.m.ops[w++] = 255;
+  if (kp.need_first_row) ma.m.ops[w++] = 2;
+  for (const auto& sw : kp.states) ma.m.ops[w++] = uint32_t(sw.op);
+  for (const auto& ag : kp.aggs) {
+    if (ag.distinct_index >= 0) ma.m.ops[kp.state_word_base() + ag.first_word] = kMergeSkip;
+  }
+  ma.m.status = head->d_status;
+  ma.state_words = W;
+  ma.first_row_word = resolved ? uint32_t(kp.first_row_word()) : 0xffffffffu;
+  ma.ncols = nc;
+  HIP_TRY(hipMemsetAsync(head->d_status, 0, 16, s));
+
+  // ---- table by table: records -> wire form -> merge -----------------------------------------
+  DevBuf<uint64_t> d_rec, d_wire, d_sizes;
+  DevBuf<RtColumn> d_cols;
+  DevBuf<uint8_t> d_heap;
+  HIP_TRY(d_rec.alloc(std::max<uint64_t>(max_n, 1) * rw_in * 8));
+  if (resolved) {
+    HIP_TRY(d_wire.alloc(std::max<uint64_t>(max_n, 1) * rw * 8));
+    HIP_TRY(d_cols.alloc(std::max<uint32_t>(nc, 1) * sizeof(RtColumn)));
+  }
+  head->m_heap.clear();
+  uint64_t rows_scanned = 0, rows_passed = 0;
+  double kernel_ms = 0;
+  for (size_t pi = 0; pi < parts.size(); ++pi) {
+    evql_query* q = parts[pi];
+    evql_table* t = q->table;
+    rows_scanned += q->stats.rows_scanned;
+    rows_passed += q->stats.rows_passed;
+    kernel_ms += q->stats.kernel_ms;
+    const uint64_t n = q->ngroups;
+    if (n == 0) continue;
+    const uint64_t nd = std::min(q->dense_n, n);
+    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
+    if (n > nd) {
+      uint64_t* d_cnt = q->d_counters + 6;
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, W, d_rec.p + nd * rw_in, n - nd,
+                                   d_cnt, s));
+    }
+    if (!resolved) {
+      HIP_TRY(launch_table_merge(ma.m, d_rec, n, s));
+      continue;
+    }
+    std::vector<RtColumn> rc(nc);
+    std::vector<uint32_t> str_cols;
+    uint64_t str_mask = 0;
+    for (uint32_t c = 0; c < nc; ++c) {
+      const ColAccess& ca = q->kp.cols[c];
+      rc[c] = RtColumn{};
+      rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
+      rc[c].mode = ca.mode;
+      rc[c].bits = ca.bits;
+      if (ca.packed) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].pages = m.d_packed_pages;
+        rc[c].base = m.d_packed;
+      } else if (ca.mode == ColAccess::SOA) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].soa = ca.string_hash ? m.d_strpos : m.d_values;
+        rc[c].tags = m.d_tags;
+      }
+      if (ca.string_hash) {
+        str_mask |= 1ull << c;
+        str_cols.push_back(c);
+      }
+    }
+    if (str_cols.size() > kMaxWireStrCols) {
+      return Status::error(EVQL_ENOTSUP, "too many string columns in a chain plan");
+    }
+    HIP_TRY(hipMemcpyAsync(d_cols, rc.data(), nc * sizeof(RtColumn), hipMemcpyHostToDevice, s));
+    ResolveArgs ra{};
+    ra.image = t->d_image;
+    ra.cols = d_cols;
+    ra.ncols = nc;
+    ra.in_words = rw_in;
+    ra.first_row_word = uint32_t(1 + kp.first_row_word());
+    ra.rank_tag = uint64_t(pi) << 44;
+    ra.in = d_rec;
+    ra.n = n;
+    ra.out = d_wire;
+    HIP_TRY(launch_resolve_records(ra, s));
+    uint64_t heap_bytes = 0;
+    if (!str_cols.empty()) {
+      WireStrArgs wa{};
+      wa.image = t->d_image;
+      wa.records = d_wire;
+      wa.n = n;
+      wa.rw = rw;
+      wa.tags_word = rw_in + nc;
+      wa.nstr = uint32_t(str_cols.size());
+      for (size_t k = 0; k < str_cols.size(); ++k) {
+        wa.word[k] = rw_in + str_cols[k];
+        wa.col[k] = str_cols[k];
+        wa.pages[k] = t->d_pages[q->kp.cols[str_cols[k]].layout_index][0];
+      }
+      HIP_TRY(d_sizes.alloc((n + 4) * 8));
+      wa.sizes = d_sizes;
+      wa.nranks = 1;
+      const uint64_t seg[2] = {0, n};
+      uint64_t* d_seg = d_sizes.p + n + 2;
+      HIP_TRY(hipMemcpyAsync(d_seg, seg, 16, hipMemcpyHostToDevice, s));
+      wa.starts = d_seg;
+      HIP_TRY(launch_wire_str_sizes(wa, s));
+      HIP_TRY(launch_exclusive_scan(d_sizes, n, d_sizes.p + n, s));
+      HIP_TRY(hipMemcpyAsync(&heap_bytes, d_sizes.p + n, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(d_heap.alloc(heap_bytes + 16));
+      wa.heap = d_heap;
+      HIP_TRY(launch_wire_str_copy(wa, s));
+    }
+    ma.str_mask = str_mask;
+    ma.heap_base = head->m_heap.size();
+    HIP_TRY(launch_table_merge_resolved(ma, d_wire, n, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (rc / seg live until here)
+    if (heap_bytes) {
+      const size_t old = head->m_heap.size();
+      head->m_heap.resize(old + heap_bytes);
+      HIP_TRY(hipMemcpy(head->m_heap.data() + old, d_heap, heap_bytes, hipMemcpyDeviceToHost));
+    }
+  }
+  if (head->m_heap.size() > kStrOffMask) {
+    return Status::error(EVQL_ENOTSUP, "chain: first-row strings exceed the offset range");
+  }
+  // ---- count_distinct: the union of the tables' pair sets ---------------------------------------
+  if (kp.n_distinct > 0) {
+    std::vector<uint64_t> counts(size_t(kp.n_distinct) * parts.size(), 0);
+    uint64_t max_total = 0;
+    for (int d = 0; d < kp.n_distinct; ++d) {
+      uint64_t tot = 0;
+      for (size_t pi = 0; pi < parts.size(); ++pi) {
+        evql_query* q = parts[pi];
+        if (!q->d_pairset[d]) continue;
+        uint64_t* d_cnt = q->d_counters + 6;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+        HIP_TRY(launch_pairset_export(q->d_pairset[d], q->pairset_cap, nullptr, 0, d_cnt, s));
+        HIP_TRY(hipMemcpyAsync(&counts[size_t(d) * parts.size() + pi], d_cnt, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        tot += counts[size_t(d) * parts.size() + pi];
+      }
+      max_total = std::max(max_total, tot);
+    }
+    uint64_t set_cap = 1 << 16;
+    while (set_cap < max_total * 2) set_cap <<= 1;
+    for (const auto& ag : kp.aggs) {
+      if (ag.distinct_index < 0) continue;
+      const int d = ag.distinct_index;
+      uint64_t tot = 0;
+      for (size_t pi = 0; pi < parts.size(); ++pi) tot += counts[size_t(d) * parts.size() + pi];
+      DevBuf<uint64_t> d_tr, d_set;
+      HIP_TRY(d_tr.alloc(std::max<uint64_t>(tot, 1) * 24));
+      uint64_t off = 0;
+      for (size_t pi = 0; pi < parts.size(); ++pi) {
+        evql_query* q = parts[pi];
+        const uint64_t np = counts[size_t(d) * parts.size() + pi];
+        if (!np) continue;
+        uint64_t* d_cnt = q->d_counters + 6;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+        HIP_TRY(launch_pairset_export(q->d_pairset[d], q->pairset_cap, d_tr.p + off * 3, np, d_cnt, s));
+        off += np;
+      }
+      HIP_TRY(d_set.alloc(set_cap * 24));
+      HIP_TRY(hipMemsetAsync(d_set, 0xff, set_cap * 24, s));
+      PairsetMergeArgs pa{};
+      pa.set = d_set;
+      pa.set_cap = set_cap;
+      pa.words = head->d_mtab;
+      pa.gcap = cap;
+      pa.nwords = mw;
+      pa.word = uint32_t(kp.state_word_base() + ag.first_word);
+      pa.key_mode = uint32_t(kp.key_mode);
+      pa.status = head->d_status;
+      HIP_TRY(launch_pairset_merge(pa, d_tr, tot, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      // the merged set replaces the head's own: PARTIAL emission reads the values of
+      // every group from it (fetch_results)
+      if (head->d_pairset[d]) hipFree(head->d_pairset[d]);
+      head->d_pairset[d] = d_set.release();
+    }
+    head->pairset_cap = set_cap;
+  }
+  uint32_t status[4] = {0};
+  HIP_TRY(hipMemcpyAsync(status, head->d_status, 16, hipMemcpyDeviceToHost, s));
+  uint64_t* d_cnt = head->d_counters + 4;
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+  HIP_TRY(launch_table_compact(head->d_mtab, cap, cap + 8, mw, nullptr, 0, d_cnt, s));
+  uint64_t ng = 0;
+  HIP_TRY(hipMemcpyAsync(&ng, d_cnt, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (status[0] & 2u) return Status::error(EVQL_ENOMEM, "merged group table full");
+  if (status[0] & 8u) return Status::error(EVQL_ENOMEM, "merged count_distinct set full");
+  head->merged = true;
+  head->ngroups = ng;
+  head->stats.num_groups = ng;
+  head->stats.rows_scanned = rows_scanned;
+  head->stats.rows_passed = rows_passed;
+  head->stats.kernel_ms = kernel_ms;
+  head->stats.total_ms = kernel_ms;
+  head->fetched = false;
+  head->emit_pos = 0;
+  return Status();
+}
+
+}  // namespace evql
 
 // ---------------------------------------------------------------------------------------
 // C ABI

@@ -279,7 +279,8 @@ evql_query::~evql_query() {
   for (auto* p : d_pairset) {
     if (p) hipFree(p);
   }
-  if (d_row_filter) hipFree(d_row_filter);
+  if (d_row_filter && row_filter_owned) hipFree(d_row_filter);
+  for (auto* c : chain) delete c;
   if (d_part_counts) hipFree(d_part_counts);
   if (d_bucket_start) hipFree(d_bucket_start);
   if (d_tuples) hipFree(d_tuples);

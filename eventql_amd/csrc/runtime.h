@@ -213,6 +213,11 @@ struct evql_query {
   std::vector<uint8_t> row_filter_host;
   uint64_t row_filter_len = 0;
   uint8_t* d_row_filter = nullptr;
+  bool row_filter_owned = true;  // false: the bits belong to an evql_lsm_chain
+  // evql_query_create_chain: this query scans the first table of a partition's chain;
+  // `chain` holds the queries of the tables behind it (owned).  After execute their
+  // groups are merged in chain order into d_mtab (exchange.cc chain_merge).
+  std::vector<evql_query*> chain;
   // partitioned path buffers
   uint32_t* d_part_counts = nullptr;
   uint64_t* d_bucket_start = nullptr;

@@ -681,24 +681,51 @@ int evql_query_set_order(evql_query_t* q, const evql_sort_spec_t* specs,
  * compacting arena, then the LSM files from the newest to the oldest.  A row is
  * scanned unless it is skipped (`__lsm_skip`, or the arena's skiplist) or a row
  * in front of it with the same `__lsm_id` was a kept update
- * (`__lsm_is_update`).  _build computes every table's filter on the device;
- * _filter hands out the bitmap (bit r of byte r/8 set <=> row r is scanned) in
- * the layout evql_plan_desc_t::row_filter_bits takes, valid until _destroy.
- * Tables must be added in scan order.  arena_skiplist: one byte per row
- * (PartitionArena::SkiplistReader::readNext), or NULL.
+ * (`__lsm_is_update`).  Tables must be added in scan order; `flags` carry the file's
+ * LSMTableRef bits (db/partition_state.proto: has_skiplist, has_updates), which decide
+ * -- exactly as partition_cursor.cc:149-155 does -- whether a file gets a filter at all:
+ *     !has_skiplist && <oldest file> && <no update remembered yet>    => none
+ *     !has_skiplist && !has_updates  && <no update remembered yet>    => none
+ * (a file without a filter is scanned whole and its updates are not remembered).
+ * arena_skiplist: one byte per row (PartitionArena::SkiplistReader::readNext) for the
+ * two arenas, NULL for files.  _build computes every table's filter on the device;
+ * _filter hands out a host copy of the bitmap (bit r of byte r/8 set <=> row r is
+ * scanned) in the layout evql_plan_desc_t::row_filter_bits takes, valid until _destroy
+ * or the next _build; *bits == NULL: the table needs no filter (setFilter is not
+ * called, partition_cursor.cc:215-217).  evql_query_create_chain reads the filters
+ * where they are, in HBM.
  * An id that is not 20 bytes long fails with EVQL_ERUNTIME "invalid SHA1Hash"
  * (util/SHA1.cc:79-85).
  */
+#define EVQL_LSM_HAS_SKIPLIST 1u /* LSMTableRef::has_skiplist: read __lsm_skip */
+#define EVQL_LSM_HAS_UPDATES 2u  /* LSMTableRef::has_updates */
 typedef struct evql_lsm_chain evql_lsm_chain_t;
 int evql_lsm_chain_create(evql_ctx_t* ctx, evql_lsm_chain_t** out);
 void evql_lsm_chain_destroy(evql_lsm_chain_t* ch);
-int evql_lsm_chain_add(evql_lsm_chain_t* ch, evql_table_t* table,
-                       int has_skip_column, const uint8_t* arena_skiplist,
-                       uint64_t arena_skiplist_len);
+int evql_lsm_chain_add(evql_lsm_chain_t* ch, evql_table_t* table, uint32_t flags,
+                       const uint8_t* arena_skiplist, uint64_t arena_skiplist_len);
 int evql_lsm_chain_build(evql_lsm_chain_t* ch);
-int evql_lsm_chain_filter(const evql_lsm_chain_t* ch, int idx,
+int evql_lsm_chain_length(const evql_lsm_chain_t* ch);
+int evql_lsm_chain_filter(evql_lsm_chain_t* ch, int idx,
                           const uint8_t** bits, uint64_t* nrows,
                           uint64_t* rows_kept);
+
+/*
+ * The operator over a whole partition: GroupByExpression (or PartialGroupByExpression)
+ * whose input is PartitionCursor (server/sql/partition_cursor.cc:34-235) -- the scans of
+ * the chain's tables one after the other, newest first, each under its row filter
+ * (AbstractCSTableScan::setFilter, sql/CSTableScan.h:36-41), feeding ONE group map.
+ * Here every table is scanned by its own fused kernel launch (tables of one partition
+ * may differ in encodings) and the per-table groups are merged on the device in chain
+ * order, so that non-aggregate select expressions keep the value of the group's first
+ * row in scan order (groupby.cc:161-172) and count_distinct counts the union of the
+ * tables' sets.  `ch` must be built and outlive the query; every other entry point
+ * (execute, next_batch, set_order, stats ...) takes the returned query as usual.
+ * EVQL_SCAN_FLAT only (PartitionCursor builds FastCSTableScan for NO_AGGREGATION
+ * statements, :197-204; anything else answers EVQL_ENOTSUP).
+ */
+int evql_query_create_chain(evql_ctx_t* ctx, evql_lsm_chain_t* ch,
+                            const evql_plan_desc_t* plan, evql_query_t** out);
 
 /* ------------------------------------------------------------------------ */
 /* build support                                                              */

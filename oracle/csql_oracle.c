@@ -952,12 +952,65 @@ static void scan_close(scan_t* sc) {
   free(sc->st.data);
 }
 
-orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
+static int scan_open(scan_t* sc, orc_table_t* t, const evql_plan_desc_t* pl);
+
+/* PartitionCursor::nextBatch, server/sql/partition_cursor.cc:56-81: the current scan's
+ * next batch; at its end the next table of the chain is opened */
+static int chain_next_batch(scan_t* sc, orc_table_t* const* tables, int ntables,
+                            const uint8_t* const* filters, const uint64_t* filter_lens,
+                            evql_plan_desc_t* plan_i, int* cur_table, svec_t* out, size_t* n) {
+  for (;;) {
+    if (flat_next_batch(sc, out, n)) return -1;
+    if (*n > 0) return 0;
+    if (*cur_table + 1 >= ntables) return 0;
+    ++*cur_table;
+    if (filters) {
+      plan_i->row_filter_bits = filters[*cur_table];
+      plan_i->row_filter_len = filters[*cur_table] ? filter_lens[*cur_table] : 0;
+    }
+    /* (rows_scanned / rows_passed keep counting across the chain) */
+    if (scan_open(sc, tables[*cur_table], plan_i)) return -1;
+  }
+}
+
+/* (re)opens the scan of one table: FastCSTableScan::execute, CSTableScan.cc:726-755 */
+static int scan_open(scan_t* sc, orc_table_t* t, const evql_plan_desc_t* pl) {
+  sc->t = t;
+  sc->plan = pl;
+  for (uint32_t i = 0; i < sc->ncols; ++i) {
+    if (sc->readers[i]) orc_column_close(sc->readers[i]);
+    sc->readers[i] = orc_column_open(t, pl->scan_columns[i]);
+    if (!sc->readers[i]) {
+      snprintf(g_qerr, sizeof(g_qerr), "column not found: %s", pl->scan_columns[i]);
+      return -1;
+    }
+    sc->colbuf[i].type = (int) pl->scan_column_types[i];
+  }
+  sc->remaining = orc_table_num_rows(t);
+  sc->consumed = 0;
+  sc->nested_opened = 0;
+  if (pl->row_end && pl->row_end < sc->remaining) sc->remaining = pl->row_end;
+  if (pl->row_begin) {
+    snprintf(g_qerr, sizeof(g_qerr), "oracle: row_begin unsupported");
+    return -1;
+  }
+  return 0;
+}
+
+/* GroupByExpression (or the bare scan) over a CHAIN of tables: the input operator is
+ * PartitionCursor (server/sql/partition_cursor.cc:56-81), which hands out the batches
+ * of one scan after the other -- newest table first -- each scan with the row filter
+ * openNextTable built for it (:197-217, setFilter).  filters[i] == NULL: no filter
+ * for table i (needs_filter == false).  One table without a filter override is the
+ * plain operator tree. */
+static orc_result_t* run_chain(orc_table_t* const* tables, int ntables,
+                               const uint8_t* const* filters, const uint64_t* filter_lens,
+                               const evql_plan_desc_t* pl0) {
   g_qerr[0] = 0;
   scan_t sc;
   memset(&sc, 0, sizeof(sc));
-  sc.t = t;
-  sc.plan = pl;
+  evql_plan_desc_t plan_i = *pl0; /* per-table copy: only the row filter differs */
+  const evql_plan_desc_t* pl = &plan_i;
   sc.ncols = pl->n_scan_columns;
   if (sc.ncols > 64) {
     snprintf(g_qerr, sizeof(g_qerr), "too many scan columns");
@@ -966,20 +1019,12 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
   sc.readers = (orc_column_t**) calloc(sc.ncols ? sc.ncols : 1, sizeof(void*));
   sc.colbuf = (svec_t*) calloc(sc.ncols ? sc.ncols : 1, sizeof(svec_t));
   st_init(&sc.st);
-  for (uint32_t i = 0; i < sc.ncols; ++i) {
-    sc.readers[i] = orc_column_open(t, pl->scan_columns[i]);
-    if (!sc.readers[i]) {
-      snprintf(g_qerr, sizeof(g_qerr), "column not found: %s",
-               pl->scan_columns[i]);
-      scan_close(&sc);
-      return NULL;
-    }
-    sc.colbuf[i].type = (int) pl->scan_column_types[i];
+  int cur_table = 0;
+  if (filters) {
+    plan_i.row_filter_bits = filters[0];
+    plan_i.row_filter_len = filters[0] ? filter_lens[0] : 0;
   }
-  sc.remaining = orc_table_num_rows(t);
-  if (pl->row_end && pl->row_end < sc.remaining) sc.remaining = pl->row_end;
-  if (pl->row_begin) {
-    snprintf(g_qerr, sizeof(g_qerr), "oracle: row_begin unsupported");
+  if (ntables < 1 || scan_open(&sc, tables[0], pl)) {
     scan_close(&sc);
     return NULL;
   }
@@ -1001,7 +1046,8 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
     } else {
       for (;;) {
         size_t n = 0;
-        if (flat_next_batch(&sc, in, &n)) {
+        if (chain_next_batch(&sc, tables, ntables, filters, filter_lens, &plan_i, &cur_table, in,
+                             &n)) {
           failed = 1;
           break;
         }
@@ -1034,7 +1080,8 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
         (void) nested_all;
       } else {
         for (uint32_t i = 0; i < nin; ++i) in[i].size = 0;
-        if (flat_next_batch(&sc, in, &n)) {
+        if (chain_next_batch(&sc, tables, ntables, filters, filter_lens, &plan_i, &cur_table, in,
+                             &n)) {
           failed = 1;
           break;
         }
@@ -1171,6 +1218,20 @@ orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
     return NULL;
   }
   return res;
+}
+
+orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* pl) {
+  return run_chain(&t, 1, NULL, NULL, pl);
+}
+
+orc_result_t* orc_query_run_chain(orc_table_t* const* tables, int ntables,
+                                  const uint8_t* const* filters, const uint64_t* filter_lens,
+                                  const evql_plan_desc_t* pl) {
+  if (pl->scan_mode != EVQL_SCAN_FLAT && ntables > 1) {
+    snprintf(g_qerr, sizeof(g_qerr), "oracle: chains of nested scans are not restated");
+    return NULL;
+  }
+  return run_chain(tables, ntables, filters, filter_lens, pl);
 }
 
 void orc_result_free(orc_result_t* r) {

@@ -75,7 +75,34 @@ void orc_lsm_free(orc_lsm_t* m) {
 
 int orc_lsm_next_table(orc_lsm_t* m, orc_table_t* t, int has_skip_column,
                        const uint8_t* arena_skip, uint8_t* filter_out) {
+  /* (a table that is always filtered: an arena, or a file that may hold updates and
+   * is not the oldest one) */
+  return orc_lsm_next_file(m, t, has_skip_column, 1, 0, arena_skip, filter_out, NULL);
+}
+
+/* One step of PartitionCursor::openNextTable for an LSM file (or an arena when
+ * arena_skip != NULL), partition_cursor.cc:134-195.  `has_skiplist` / `has_updates`
+ * are the LSMTableRef flags of the file (db/partition_state.proto), `is_oldest` says
+ * tblidx == 0.  A file needs no filter -- every row is scanned and, NOTE, its updates
+ * are not remembered either -- when (:149-155)
+ *     !has_skiplist && tblidx == 0 && id_set.empty()
+ *  || !has_skiplist && !has_updates && id_set.empty()
+ * *needs_filter_out receives whether setFilter was called (:215-217). */
+int orc_lsm_next_file(orc_lsm_t* m, orc_table_t* t, int has_skiplist, int has_updates,
+                      int is_oldest, const uint8_t* arena_skip, uint8_t* filter_out,
+                      int* needs_filter_out) {
   const uint64_t n = orc_table_num_rows(t);
+  int needs_filter = 1;
+  if (!arena_skip) {
+    if (!has_skiplist && is_oldest && m->n == 0) needs_filter = 0;
+    if (!has_skiplist && !has_updates && m->n == 0) needs_filter = 0;
+  }
+  if (needs_filter_out) *needs_filter_out = needs_filter;
+  if (!needs_filter) {
+    memset(filter_out, 1, n); /* std::vector<bool> filter(numRecords, true), :161 */
+    return 0;
+  }
+  const int has_skip_column = has_skiplist && !arena_skip;
   orc_column_t* id_col = orc_column_open(t, "__lsm_id");
   orc_column_t* upd_col = orc_column_open(t, "__lsm_is_update");
   orc_column_t* skip_col = has_skip_column ? orc_column_open(t, "__lsm_skip") : NULL;

@@ -75,6 +75,13 @@ typedef struct orc_result orc_result_t;
  * (or the bare scan when plan->n_select == 0 && plan->n_group == 0) on one
  * thread, exactly in reference order.  Returns NULL on error. */
 orc_result_t* orc_query_run(orc_table_t* t, const evql_plan_desc_t* plan);
+/* the same operator tree over PartitionCursor (server/sql/partition_cursor.cc:56-81):
+ * the flat scans of `ntables` tables one after the other, table i under the row filter
+ * filters[i] (bit r of byte r/8; NULL = none), one group map across all of them */
+orc_result_t* orc_query_run_chain(orc_table_t* const* tables, int ntables,
+                                  const uint8_t* const* filters,
+                                  const uint64_t* filter_lens,
+                                  const evql_plan_desc_t* plan);
 void orc_result_free(orc_result_t* r);
 int orc_result_num_columns(const orc_result_t* r);
 int orc_result_column_type(const orc_result_t* r, int col);
@@ -104,6 +111,11 @@ orc_lsm_t* orc_lsm_create(void);
 void orc_lsm_free(orc_lsm_t* m);
 int orc_lsm_next_table(orc_lsm_t* m, orc_table_t* t, int has_skip_column,
                        const uint8_t* arena_skip, uint8_t* filter_out);
+/* the same step with the file's LSMTableRef flags and the two "no filter needed"
+ * shortcuts of partition_cursor.cc:149-155 (see lsm_oracle.c) */
+int orc_lsm_next_file(orc_lsm_t* m, orc_table_t* t, int has_skiplist, int has_updates,
+                      int is_oldest, const uint8_t* arena_skip, uint8_t* filter_out,
+                      int* needs_filter_out);
 
 /* GroupByMergeExpression (groupby.cc:528-672) over `nframes` partial-aggregate
  * frame payloads (varuint flags, varuint count, rows); only plan->select_exprs

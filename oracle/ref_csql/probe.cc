@@ -29,6 +29,15 @@
  *   TIME <n> <statement>                    run it n times, report best seconds
  *   WRITE <file.cst> <nrows> <seed>         SURVEY 8c(ii) xorshift table through
  *                                           the reference's own CSTableWriter
+ *   PARTITION <name> <dir> <file>:<skiplist>:<updates> ...
+ *                                           a table whose scans are the reference's own
+ *                                           eventql::PartitionCursor (server/sql/
+ *                                           partition_cursor.cc) over a PartitionSnapshot
+ *                                           with these lsm_tables (OLDEST first, as in
+ *                                           PartitionState; <dir>/<file>.cst; the two flags
+ *                                           are LSMTableRef::has_skiplist / has_updates);
+ *                                           the same chain is registered with the GPU
+ *                                           registry
  */
 #include <math.h>
 #include <stdio.h>
@@ -50,8 +59,13 @@
 #include <eventql/sql/runtime/tablerepository.h>
 #include <eventql/sql/statements/select/groupby.h>
 #include <eventql/util/SHA1.h>
+#include <eventql/db/file_tracker.h>
+#include <eventql/db/partition_snapshot.h>
+#include <eventql/db/table.h>
+#include <eventql/server/sql/partition_cursor.h>
 #include "gpu_bridge.h"
 #include "gpu_group_by_scan.h"
+#include "gpu_partition.h"
 
 using namespace evql_adapter;
 
@@ -70,6 +84,24 @@ struct DremelScanProvider : public csql::CSTableScanProvider {
     return Option<ScopedPtr<csql::TableExpression>>(ScopedPtr<csql::TableExpression>(
         new csql::CSTableScan(txn, ctx, node, cstable_file_)));
   }
+};
+
+/* A partition of an evqld table: the scan is the reference's own PartitionCursor over a
+ * PartitionSnapshot (db/partition_snapshot.h:37-69), built exactly as
+ * TableScan::openLocalPartition does (server/sql/table_scan.cc:116-144).  The schema
+ * comes from the newest file (CSTableScanProvider::describe). */
+struct PartitionProvider : public csql::CSTableScanProvider {
+  PartitionProvider(const String& name, const String& newest_file,
+                    RefPtr<eventql::PartitionSnapshot> snap)
+      : csql::CSTableScanProvider(name, newest_file), snap_(snap) {}
+  Option<ScopedPtr<csql::TableExpression>> buildSequentialScan(
+      csql::Transaction* txn, csql::ExecutionContext* ctx,
+      RefPtr<csql::SequentialScanNode> node) const override {
+    if (node->tableName() != table_name_) return None<ScopedPtr<csql::TableExpression>>();
+    return Option<ScopedPtr<csql::TableExpression>>(ScopedPtr<csql::TableExpression>(
+        new eventql::PartitionCursor(txn, ctx, RefPtr<eventql::Table>(), snap_, node)));
+  }
+  RefPtr<eventql::PartitionSnapshot> snap_;
 };
 
 std::string jsonString(const char* s, size_t n) {
@@ -298,7 +330,11 @@ struct Probe {
   std::shared_ptr<GpuTableRegistry> registry;
   struct Tbl {
     std::string name, file, kind;
+    RefPtr<eventql::PartitionSnapshot> snap; /* kind == "partition" */
   };
+  /* what a PartitionSnapshot's constructor touches of the server (file refcounts) */
+  std::unique_ptr<eventql::FileTracker> file_tracker;
+  eventql::DatabaseContext dbctx{};
   std::vector<Tbl> tables;
   ProbeScheduler* scheduler = nullptr; /* owned by the runtime */
 
@@ -329,7 +365,9 @@ struct Probe {
       auto txn = runtime->newTransaction();
       auto repo = mkScoped(new csql::TableRepository());
       for (const auto& t : tables) {
-        if (t.kind == "dremel") {
+        if (t.kind == "partition") {
+          repo->addProvider(new PartitionProvider(t.name, t.file, t.snap));
+        } else if (t.kind == "dremel") {
           repo->addProvider(new DremelScanProvider(t.name, t.file));
         } else {
           repo->addProvider(new csql::CSTableScanProvider(t.name, t.file));
@@ -446,6 +484,54 @@ int main(int argc, char** argv) {
       if (!replaced) probe.tables.push_back(t);
       probe.registry->registerTable(t.name, t.file,
                                     t.kind == "dremel" ? ScanKind::DREMEL : ScanKind::FAST, tag);
+    } else if (cmd == "PARTITION") {
+      Probe::Tbl t;
+      std::string dir, spec;
+      is >> t.name >> dir;
+      t.kind = "partition";
+      if (!probe.file_tracker) {
+        probe.file_tracker.reset(new eventql::FileTracker(dir));
+        probe.dbctx.file_tracker = probe.file_tracker.get();
+      }
+      eventql::PartitionState state;
+      state.set_tsdb_namespace("probe");
+      state.set_partition_key(SHA1::compute(t.name).data(), SHA1Hash::kSize);
+      state.set_table_key(t.name);
+      uint64_t seq = 1;
+      while (is >> spec) {
+        /* <file>:<has_skiplist>:<has_updates>, oldest first like PartitionState::lsm_tables */
+        size_t c2 = spec.rfind(':'), c1 = spec.rfind(':', c2 - 1);
+        std::string fname = spec.substr(0, c1);
+        bool skiplist = spec[c1 + 1] == '1', updates = spec[c2 + 1] == '1';
+        auto ref = state.add_lsm_tables();
+        ref->set_filename(fname);
+        ref->set_first_sequence(seq);
+        ref->set_last_sequence(seq);
+        ref->set_has_skiplist(skiplist);
+        ref->set_has_updates(updates);
+        ++seq;
+        t.file = dir + "/" + fname + ".cst"; /* ends as the newest */
+      }
+      state.set_lsm_sequence(seq);
+      t.snap = mkRef(new eventql::PartitionSnapshot(state, dir, "", &probe.dbctx, 0));
+      bool replaced = false;
+      for (auto& e : probe.tables) {
+        if (e.name == t.name) {
+          e = t;
+          replaced = true;
+        }
+      }
+      if (!replaced) probe.tables.push_back(t);
+      /* the GPU registry finds the chain the way evqld's would: through a resolver that
+       * maps the scan's table name to the partition's snapshot (gpu_partition.h) */
+      Probe* pp = &probe;
+      probe.registry->setResolver(partitionResolver(
+          [pp](const std::string& name) -> RefPtr<eventql::PartitionSnapshot> {
+            for (const auto& e : pp->tables) {
+              if (e.name == name && e.kind == "partition") return e.snap;
+            }
+            return RefPtr<eventql::PartitionSnapshot>();
+          }));
     } else if (cmd == "CACHE") {
       std::string dir;
       is >> dir;

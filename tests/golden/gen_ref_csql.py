@@ -100,13 +100,24 @@ def main(argv):
             by_table.setdefault(c["table"], []).append(c)
         out_cases = []
         for table, cs in by_table.items():
-            if table not in files:
-                img, _, kind = refcases.table_image(table)
-                path = os.path.join(tmp, table + ".cst")
-                open(path, "wb").write(img)
-                files[table] = (path, kind)
-            path, kind = files[table]
-            cmds = ["TABLE t %s %s" % (path, kind), "DUMP on", "ROWS on", "MODE cpu"]
+            if table.startswith("lsm:"):
+                # a partition: the reference's own PartitionCursor over a PartitionSnapshot
+                # with these lsm_tables (probe.cc PARTITION)
+                if table not in files:
+                    specs = []
+                    for fname, img, skl, upd, _ in refcases.partition_files(table):
+                        open(os.path.join(tmp, fname + ".cst"), "wb").write(img)
+                        specs.append("%s:%d:%d" % (fname, skl, upd))
+                    files[table] = ("PARTITION t %s %s" % (tmp, " ".join(specs)), "fast")
+                table_cmd, kind = files[table]
+            else:
+                if table not in files:
+                    img, _, kind = refcases.table_image(table)
+                    path = os.path.join(tmp, table + ".cst")
+                    open(path, "wb").write(img)
+                    files[table] = ("TABLE t %s %s" % (path, kind), kind)
+                table_cmd, kind = files[table]
+            cmds = [table_cmd, "DUMP on", "ROWS on", "MODE cpu"]
             cmds += ["SQL " + c["sql"] for c in cs]
             cmds += ["DUMP off", "MODE cpu partial"]
             cmds += ["SQL " + c["sql"] for c in cs]
@@ -126,7 +137,10 @@ def main(argv):
                         oc["result"] = dict(ok=None, undefined="CSTableScan column order")
                 # a global aggregate has no group key: the reference's partial
                 # operator still emits one row; keep it
-                oc["partial"] = pack_partial(part)
+                if "select" in c["kw"]:
+                    oc["partial"] = pack_partial(part)
+                else:  # a bare scan has no partial form
+                    oc["partial"] = dict(ok=False, error="bare scan")
                 out_cases.append(oc)
         out_cases.sort(key=lambda c: c["id"])
         doc = dict(

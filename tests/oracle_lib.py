@@ -466,6 +466,75 @@ def oracle_lsm_filters(images, has_skip_column, arena_skips=None):
     return out
 
 
+def oracle_partition_filters(files_oldest_first):
+    """PartitionCursor::openNextTable over the LSM files of a partition
+    (tests/lsm_tables.partition): bool array per file in SCAN order (newest first), None
+    where the cursor does not call setFilter (orc_lsm_next_file)"""
+    import numpy as np
+    L = oracle()
+    L.orc_lsm_create.restype = C.c_void_p
+    L.orc_lsm_free.argtypes = [C.c_void_p]
+    L.orc_lsm_next_file.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                    C.c_char_p, C.POINTER(C.c_int)]
+    m = L.orc_lsm_create()
+    out = []
+    try:
+        n = len(files_oldest_first)
+        for k, (_, img, skl, upd, _) in enumerate(reversed(files_oldest_first)):
+            buf = bytes(img)
+            t = L.orc_table_open_image(buf, len(buf))
+            if not t:
+                raise IOError(L.orc_last_error().decode())
+            try:
+                rows = L.orc_table_num_rows(t)
+                res = C.create_string_buffer(max(1, rows))
+                needs = C.c_int(0)
+                rc = L.orc_lsm_next_file(m, t, int(skl), int(upd), int(n - 1 - k == 0), None, res,
+                                         C.byref(needs))
+                if rc == -2:
+                    raise RuntimeError("invalid SHA1Hash")
+                if rc:
+                    raise IOError("oracle lsm read error")
+                out.append(np.frombuffer(res.raw[:rows], np.uint8).astype(bool)
+                           if needs.value else None)
+            finally:
+                L.orc_table_close(t)
+    finally:
+        L.orc_lsm_free(m)
+    return out
+
+
+def oracle_run_chain(images_scan_order, filters, plan):
+    """GroupByExpression / bare scan over PartitionCursor (orc_query_run_chain): the
+    tables in scan order, filters[i] a bool array or None"""
+    import numpy as np
+    L = oracle()
+    n = len(images_scan_order)
+    bufs = [bytes(i) for i in images_scan_order]
+    tabs = [L.orc_table_open_image(b, len(b)) for b in bufs]
+    if not all(tabs):
+        raise IOError(L.orc_last_error().decode())
+    packed = [None if f is None else np.packbits(np.asarray(f, bool), bitorder="little").tobytes() + b"\0"
+              for f in filters]
+    L.orc_query_run_chain.restype = C.c_void_p
+    L.orc_query_run_chain.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_char_p),
+                                      C.POINTER(C.c_uint64), C.c_void_p]
+    tarr = (C.c_void_p * n)(*tabs)
+    farr = (C.c_char_p * n)(*packed)
+    larr = (C.c_uint64 * n)(*[0 if f is None else len(f) for f in filters])
+    try:
+        r = L.orc_query_run_chain(tarr, n, farr, larr, C.byref(plan.desc))
+        if not r:
+            raise RuntimeError(L.orc_query_error().decode())
+        try:
+            return _collect(L, r)
+        finally:
+            L.orc_result_free(r)
+    finally:
+        for t in tabs:
+            L.orc_table_close(t)
+
+
 def oracle_merge(plan, frames):
     """GroupByMergeExpression restatement over frame payloads"""
     L = oracle()

@@ -90,6 +90,14 @@ def suite(name):
     return deco
 
 
+def partition_files(key):
+    """"lsm:<name>" -> [(file name, image, has_skiplist, has_updates, columns)], oldest
+    first (tests/lsm_tables.py)"""
+    import lsm_tables
+    assert key.startswith("lsm:")
+    return lsm_tables.partition(key[4:])
+
+
 def table_image(key):
     """(cstable image bytes, schema, probe scan kind) of a fixture table"""
     import nested_tables as N
@@ -246,11 +254,59 @@ def nested_cases():
     return out
 
 
+LSM = dict(uint_cols=["k", "a", "n", "rid"], float_cols=["v"], bool_cols=[],
+           key_cols=["k", "s", "n"], first_cols=["a", "s", "v", "rid"],
+           lits=[0, 1, 2, 7, 13, 1000, 30000, 65535, 1 << 33])
+
+
+@suite("lsm")
+def lsm_cases():
+    """GROUP BY over eventql::PartitionCursor (server/sql/partition_cursor.cc): chains of
+    LSM files under the row filters openNextTable builds.  "scan" returns the rid of
+    every row the cursor lets through -- the filters themselves, row by row."""
+    import lsm_tables
+    k, a, n, s, rid = [_c(x) for x in ("k", "a", "n", "s", "rid")]
+    named = [
+        ("count", dict(select=[Agg("count", Lit(1))], group_by=[])),
+        ("group-k", dict(select=[k, Agg("count", Lit(1)), Agg("sum", a)], group_by=[k])),
+        # non-aggregates keep the FIRST row in scan order: newest file first
+        ("first-row", dict(select=[k, rid, a, s, Agg("count", Lit(1))], group_by=[k])),
+        ("string-key", dict(select=[s, Agg("count", Lit(1)), Agg("sum", a)], group_by=[s])),
+        ("where", dict(select=[k, Agg("sum", a), Agg("count", Lit(1))], group_by=[k],
+                       where=Call("logical_and", Call("gt", a, Lit(30000)),
+                                  Call("lt", n, Lit(10_000_000_000))))),
+        ("distinct", dict(select=[k, Agg("count_distinct", a)], group_by=[k])),
+        ("two-keys", dict(select=[k, s, Agg("count", Lit(1))], group_by=[k, s])),
+        ("high-card", dict(select=[Call("mod", rid, Lit(977)), Agg("count", Lit(1)), Agg("sum", a)],
+                           group_by=[Call("mod", rid, Lit(977))])),
+    ]
+    out = []
+    for pi, pname in enumerate(sorted(lsm_tables.PARTITIONS)):
+        table = "lsm:" + pname
+        out.append(dict(id="lsm-%s-scan" % pname, table=table, kw=dict(scan_select=[rid]),
+                        sql="select rid from t;", scan_mode=K.SCAN_FLAT))
+        for cid, kw in named:
+            c = _case("lsm-%s-%s" % (pname, cid), table, kw, lsm_tables.LSM_SCHEMA)
+            assert c is not None, cid
+            out.append(c)
+        for seed in range(4 if pname == "big" else 8):
+            g = RefGen(80_000 + 100 * pi + seed, **LSM)
+            g.count_cols = ["k", "a", "n", "v"]
+            c = _case("lsm-%s-r%02d" % (pname, seed), table, g.plan_kwargs([1]),
+                      lsm_tables.LSM_SCHEMA)
+            if c:
+                out.append(c)
+    return out
+
+
 def all_cases():
     return {name: fn() for name, fn in SUITES.items()}
 
 
 def table_schema(key):
     import nested_tables as N
+    if key.startswith("lsm:"):
+        import lsm_tables
+        return lsm_tables.LSM_SCHEMA
     return {"mixed": T.MIXED_SCHEMA, "ranges": T.RANGES_SCHEMA, "survey": T.SURVEY_SCHEMA,
             "items": N.ITEMS_SCHEMA, "testtbl": N.NESTED_SCHEMA}[key]

@@ -99,16 +99,17 @@ def test_oracle_restatement_against_the_python_model(built):
 
 @pytest.mark.gpu
 def test_device_filters_match_the_oracle(ctx):
-    chain = make_chain(11, [70_001, 1, 30_000, 150_000], 60_000)
-    # table 1 plays an arena (skiplist from memory, no skip column); table 2 has
-    # no skiplist at all; nullable flag columns go through the decode-to-SoA path
-    arena_skip = np.array([0], np.uint8)
-    imgs = [lsm_table(*chain[0]),
-            lsm_table(*chain[1], with_skip_column=False),
+    chain = make_chain(11, [3, 70_001, 30_000, 150_000], 60_000)
+    # table 0 plays an arena (skiplist from memory, no skip column; arenas come first,
+    # partition_cursor.cc:91-132); table 2 has no skiplist at all; nullable flag columns
+    # go through the decode-to-SoA path
+    arena_skip = np.array([0, 1, 0], np.uint8)
+    imgs = [lsm_table(*chain[0], with_skip_column=False),
+            lsm_table(*chain[1]),
             lsm_table(*chain[2], with_skip_column=False, nullable_flags=True),
             lsm_table(*chain[3])]
-    has_skip = [True, False, False, True]
-    skips = [None, arena_skip, None, None]
+    has_skip = [False, True, False, True]
+    skips = [arena_skip, None, None, None]
     exp = O.oracle_lsm_filters(imgs, has_skip, skips)
     tables = [ctx.open_image(i) for i in imgs]
     ch = E.LsmChain(ctx)
