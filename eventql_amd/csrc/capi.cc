@@ -652,6 +652,24 @@ int evql_query_finish(evql_query_t* q) {
 int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user) {
   API_TRY
   if (hb && hb(user) != 0) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
+  // (the cardinality probe of a hint-less plan and the re-runs after a full table happen
+  // inside launch / finish: they beat through the query)
+  struct HbScope {
+    std::vector<evql_query*> qs;
+    ~HbScope() {
+      for (evql_query* p : qs) {
+        p->hb = nullptr;
+        p->hb_user = nullptr;
+      }
+    }
+  } hbs;
+  hbs.qs.push_back(q);
+  for (evql_query* c : q->chain) hbs.qs.push_back(c);
+  for (evql_query* p : hbs.qs) {
+    p->hb = hb;
+    p->hb_user = user;
+    p->hb_abort = false;
+  }
   Status st = launch_all(q);
   if (!st.ok()) return ret(st);
   // GroupByExpression::execute calls txn_->triggerHeartbeat() once per input batch
@@ -673,6 +691,7 @@ int evql_query_execute(evql_query_t* q, evql_heartbeat_fn hb, void* user) {
   }
   st = finish_all(q);
   if (!st.ok()) return ret(st);
+  for (evql_query* p : hbs.qs) aborted = aborted || p->hb_abort;
   if (aborted || (hb && hb(user) != 0)) return fail(EVQL_ERUNTIME, "query aborted by heartbeat");
   return EVQL_OK;
   API_CATCH

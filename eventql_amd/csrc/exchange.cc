@@ -41,6 +41,8 @@ struct evql_hub {
   std::vector<const uint64_t*> host_send;              // all_gather
   std::vector<const uint64_t*> dev_send;               // all_to_all: packed send buffers
   std::vector<std::vector<uint64_t>> send_counts;      // [src][dst]
+  int error = EVQL_OK;                                 // first failure of any rank (sticky)
+  std::string error_msg;
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const uint64_t gen = generation;
@@ -105,6 +107,25 @@ struct WsBuf {
 
 namespace {
 
+// Every rank reaches every barrier of a collective even after a local failure (a rank
+// that returned early would leave its peers waiting on the condition variable for
+// ever); the first error is kept in the hub and every rank reports it.  An exchange
+// error is fatal to the hub / communicator: the caller tears it down.
+int hub_fail(evql_hub* h, int code, const char* msg) {
+  std::unique_lock<std::mutex> lk(h->mu);
+  if (h->error == EVQL_OK) {
+    h->error = code;
+    h->error_msg = msg;
+  }
+  return code;
+}
+
+int hub_result(evql_hub* h) {
+  std::unique_lock<std::mutex> lk(h->mu);
+  if (h->error != EVQL_OK) return fail(h->error, h->error_msg);
+  return EVQL_OK;
+}
+
 int hub_all_gather(void* user, const uint64_t* send, uint64_t n, uint64_t* recv) {
   evql_exchange* x = static_cast<evql_exchange*>(user);
   evql_hub* h = x->hub;
@@ -112,7 +133,7 @@ int hub_all_gather(void* user, const uint64_t* send, uint64_t n, uint64_t* recv)
   h->barrier();
   for (int r = 0; r < x->nranks; ++r) memcpy(recv + uint64_t(r) * n, h->host_send[r], n * 8);
   h->barrier();
-  return EVQL_OK;
+  return hub_result(h);
 }
 
 int hub_all_to_all(void* user, const uint64_t* d_send, const uint64_t* send_counts, uint64_t* d_recv,
@@ -121,25 +142,32 @@ int hub_all_to_all(void* user, const uint64_t* d_send, const uint64_t* send_coun
   evql_hub* h = x->hub;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the send buffer has to be complete before another rank's thread reads it
-  if (hipStreamSynchronize(s) != hipSuccess) return fail(EVQL_EDEVICE, "hub: stream sync failed");
+  if (hipStreamSynchronize(s) != hipSuccess) hub_fail(h, EVQL_EDEVICE, "hub: stream sync failed");
   h->dev_send[x->rank] = d_send;
   h->send_counts[x->rank].assign(send_counts, send_counts + x->nranks);
   h->barrier();
   uint64_t roff = 0;
-  for (int r = 0; r < x->nranks; ++r) {
+  bool ok = hub_result(h) == EVQL_OK;
+  for (int r = 0; ok && r < x->nranks; ++r) {
     uint64_t soff = 0;
     for (int d = 0; d < x->rank; ++d) soff += h->send_counts[r][d];
     const uint64_t cnt = h->send_counts[r][x->rank];
-    if (cnt != recv_counts[r]) return fail(EVQL_ERUNTIME, "hub: counts disagree");
+    if (cnt != recv_counts[r]) {
+      hub_fail(h, EVQL_ERUNTIME, "hub: counts disagree");
+      ok = false;
+      break;
+    }
     if (cnt && hipMemcpyAsync(d_recv + roff, h->dev_send[r] + soff, cnt * 8, hipMemcpyDefault, s) !=
                    hipSuccess) {
-      return fail(EVQL_EDEVICE, "hub: device copy failed");
+      hub_fail(h, EVQL_EDEVICE, "hub: device copy failed");
+      ok = false;
+      break;
     }
     roff += cnt;
   }
-  if (hipStreamSynchronize(s) != hipSuccess) return fail(EVQL_EDEVICE, "hub: stream sync failed");
+  if (hipStreamSynchronize(s) != hipSuccess) hub_fail(h, EVQL_EDEVICE, "hub: stream sync failed");
   h->barrier();  // nobody reuses a send buffer before everyone has copied from it
-  return EVQL_OK;
+  return hub_result(h);
 }
 
 int rccl_all_gather(void* user, const uint64_t* send, uint64_t n, uint64_t* recv) {
@@ -168,14 +196,27 @@ int rccl_all_to_all(void* user, const uint64_t* d_send, const uint64_t* send_cou
   hipStream_t s = static_cast<hipStream_t>(stream);
   // xGMI is point to point: one send and one receive per peer, all in flight at once
   if (ncclGroupStart() != ncclSuccess) return fail(EVQL_EDEVICE, "ncclGroupStart failed");
+  ncclResult_t rc = ncclSuccess;
   uint64_t soff = 0, roff = 0;
   for (int r = 0; r < x->nranks; ++r) {
-    if (send_counts[r]) ncclSend(d_send + soff, send_counts[r], ncclUint64, r, x->comm, s);
-    if (recv_counts[r]) ncclRecv(d_recv + roff, recv_counts[r], ncclUint64, r, x->comm, s);
+    // (a failed call inside the group: the group is still closed, so that the calls
+    // already queued are matched on the peers, and the error is reported afterwards)
+    if (send_counts[r] && rc == ncclSuccess) {
+      rc = ncclSend(d_send + soff, send_counts[r], ncclUint64, r, x->comm, s);
+    }
+    if (recv_counts[r] && rc == ncclSuccess) {
+      rc = ncclRecv(d_recv + roff, recv_counts[r], ncclUint64, r, x->comm, s);
+    }
     soff += send_counts[r];
     roff += recv_counts[r];
   }
-  if (ncclGroupEnd() != ncclSuccess) return fail(EVQL_EDEVICE, "ncclGroupEnd failed");
+  const ncclResult_t rce = ncclGroupEnd();
+  if (rc != ncclSuccess) {
+    return fail(EVQL_EDEVICE, std::string("ncclSend / ncclRecv failed: ") + ncclGetErrorString(rc));
+  }
+  if (rce != ncclSuccess) {
+    return fail(EVQL_EDEVICE, std::string("ncclGroupEnd failed: ") + ncclGetErrorString(rce));
+  }
   return EVQL_OK;
 }
 

@@ -1442,6 +1442,11 @@ static Status compile_plan_kernels(evql_query* q) {
 // is re-shaped for the partitioned path (choose_launch_shape) in the same execute.
 static const uint64_t kProbeMinRows = 8ull << 20;  // below this the probe cannot pay
 static const uint64_t kProbeRows = 256ull << 10;
+static const uint64_t kProbeSegments = 16;  // row ranges spread evenly over the scan range
+
+static void beat(evql_query* q) {
+  if (q->hb && q->hb(q->hb_user) != 0) q->hb_abort = true;
+}
 
 static Status probe_cardinality(evql_query* q) {
   evql_table* t = q->table;
@@ -1449,15 +1454,27 @@ static Status probe_cardinality(evql_query* q) {
   const uint64_t begin = std::min(q->row_begin, nrows);
   const uint64_t end = q->row_end ? std::min(q->row_end, nrows) : nrows;
   if (end - begin < kProbeMinRows) return Status();
-  const uint64_t saved_end = q->row_end;
-  q->row_end = begin + kProbeRows;
+  const uint64_t saved_begin = q->row_begin, saved_end = q->row_end;
   // room for one group per sampled row
   Status st = alloc_gtab(q, 4 * kProbeRows);
   if (!st.ok()) return st;
-  st = query_launch(q);
-  if (st.ok()) st = query_finish(q);
+  // The sample is kProbeSegments row ranges spread over the whole scan range, all
+  // aggregated into one table: a prefix alone misjudges tables whose keys follow the
+  // row order (time-ordered partitions: a prefix of a sorted key column holds one group).
+  const uint64_t seg_rows = kProbeRows / kProbeSegments;
+  const uint64_t stride = (end - begin) / kProbeSegments;
+  for (uint64_t sg = 0; sg < kProbeSegments && st.ok(); ++sg) {
+    q->row_begin = begin + sg * stride;
+    q->row_end = q->row_begin + seg_rows;
+    q->keep_table = sg > 0;
+    st = query_launch(q);
+    if (st.ok()) st = query_finish(q);
+    beat(q);
+  }
+  q->keep_table = false;
+  q->row_begin = saved_begin;
   q->row_end = saved_end;
-  if (!st.ok()) return st;  // (a division by zero in the prefix is one in the whole scan)
+  if (!st.ok()) return st;  // (a division by zero in the sample is one in the whole scan)
   const double p = double(q->stats.rows_passed), d = double(q->stats.num_groups);
   // the group table is rebuilt for the real run
   hipFree(q->d_gtab);
@@ -1653,22 +1670,26 @@ Status query_launch(evql_query* q) {
     if (!st.ok()) return st;
   }
   const uint64_t stride = q->gcap + 8;
-  TableInitArgs ia{};
-  ia.words = q->d_gtab;
-  ia.stride = stride;
-  ia.nwords = uint32_t(kp.words_per_slot());
-  ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
-  int w = 1;
-  if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
-  if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
-  for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
-  HIP_TRY(launch_table_init(ia, s));
-  HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
-  HIP_TRY(hipMemsetAsync(q->d_counters, 0, 64, s));
+  if (!q->keep_table) {
+    TableInitArgs ia{};
+    ia.words = q->d_gtab;
+    ia.stride = stride;
+    ia.nwords = uint32_t(kp.words_per_slot());
+    ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
+    int w = 1;
+    if (kp.has_ident2()) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+    if (kp.need_first_row) ia.identity[w++] = 0xFFFFFFFFFFFFFFFFull;
+    for (const auto& sw : kp.states) ia.identity[w++] = word_identity(sw.op);
+    HIP_TRY(launch_table_init(ia, s));
+    HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
+    HIP_TRY(hipMemsetAsync(q->d_counters, 0, 64, s));
+  } else {
+    HIP_TRY(hipMemsetAsync(q->d_counters + 4, 0, 8, s));  // (the group count is recounted)
+  }
 
   HostArgs a{};
   fill_host_args(q, &a);
-  if (kp.n_distinct > 0) {
+  if (kp.n_distinct > 0 && !q->keep_table) {
     // count_distinct pair sets: emptied before every launch
     if (q->pairset_cap == 0) {
       const uint64_t span = a.row_end > a.row_begin ? a.row_end - a.row_begin : 0;
@@ -1682,9 +1703,11 @@ Status query_launch(evql_query* q) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_pairset[i]), q->pairset_cap * 3 * 8));
       }
       HIP_TRY(hipMemsetAsync(q->d_pairset[i], 0xff, q->pairset_cap * 3 * 8, s));
-      a.pairset[i] = q->d_pairset[i];
-      a.pairset_cap[i] = q->pairset_cap;
     }
+  }
+  for (int i = 0; i < kp.n_distinct; ++i) {
+    a.pairset[i] = q->d_pairset[i];
+    a.pairset_cap[i] = q->pairset_cap;
   }
   if (kp.partitioned && a.ntiles > 0) {
     // count -> per-bucket prefix -> scatter -> per-bucket LDS aggregation
@@ -1803,10 +1826,27 @@ Status query_finish(evql_query* q) {
       // group table / count_distinct pair set / dense record buffer too small: grow
       // and run again
       Status st;
+      beat(q);
       if (status[0] & 16u) {
         hipFree(q->d_dense);
         q->d_dense = nullptr;
         q->groups_hint = std::max<uint64_t>(q->groups_hint, 1024) * 4;
+        if (q->kp.partitioned && !q->keep_table) {
+          // the estimate was off by more than the headroom: bucket bits and launch shape
+          // follow the corrected group count (too few buckets overflow every LDS table)
+          const int old_bits = q->kp.part_bits;
+          choose_launch_shape(&q->kp, q->groups_hint);
+          if (q->kp.part_bits != old_bits || !q->kp.partitioned) {
+            for (void* p : {(void*) q->d_part_counts, (void*) q->d_bucket_start, (void*) q->d_part_cursors}) {
+              if (p) hipFree(p);
+            }
+            q->d_part_counts = nullptr;
+            q->d_bucket_start = nullptr;
+            q->d_part_cursors = nullptr;
+            Status stc = compile_plan_kernels(q);
+            if (!stc.ok()) return stc;
+          }
+        }
       }
       if (status[0] & 2u) {
         st = alloc_gtab(q, q->gcap * 4);

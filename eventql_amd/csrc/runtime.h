@@ -280,6 +280,13 @@ struct evql_query {
   uint64_t pairset_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool probed = false;    // cardinality probe done (plans without groups_hint)
+  bool keep_table = false;  // launch without emptying the group table / counters (the
+                            // cardinality probe aggregates several row ranges into one)
+  // heartbeat of the running evql_query_execute: also beaten between the launches of the
+  // cardinality probe and between the re-runs after a full table
+  int (*hb)(void*) = nullptr;
+  void* hb_user = nullptr;
+  bool hb_abort = false;
   bool launched = false;
   bool executed = false;
   bool fetched = false;  // groups copied to the host (lazy, on first nextBatch)

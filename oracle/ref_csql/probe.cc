@@ -23,6 +23,14 @@
  *                                           registry; a tag makes partial results cacheable)
  *   CACHE <dir>                             install a csql::QueryCache (stores at first use)
  *   MODE cpu|gpu|gpuscan [partial] [strict] which operators execute
+ *   MODE evqld [strict]                     the scheduler evqld would install:
+ *                                           GpuSchedulerT<eventql::Scheduler>, serving the
+ *                                           data-node half of a distributed GROUP BY (every
+ *                                           GroupByNode arrives marked partial, as
+ *                                           EVQL_OP_QUERY_PARTIALAGGR delivers it): lowered
+ *                                           plans run PartialGroupByExpression's GPU twin,
+ *                                           the others eventql::Scheduler's own
+ *                                           buildPartialGroupByExpression
  *   DUMP on|off                             include the compiled programs
  *   ROWS on|off                             include result rows (off: count only)
  *   SQL <statement>                         run it
@@ -63,6 +71,8 @@
 #include <eventql/db/partition_snapshot.h>
 #include <eventql/db/table.h>
 #include <eventql/server/sql/partition_cursor.h>
+#include <eventql/server/sql/scheduler.h>
+#include <eventql/config/process_config.h>
 #include "gpu_bridge.h"
 #include "gpu_group_by_scan.h"
 #include "gpu_partition.h"
@@ -238,13 +248,24 @@ struct ProbeState {
 };
 ProbeState g_state;
 
+/* what the probe reads back from whichever scheduler is installed */
+struct DecisionSource {
+  virtual ~DecisionSource() {}
+  virtual const std::vector<GpuLowering::Decision>& probeDecisions() const = 0;
+  virtual void probeClear() = 0;
+  virtual uint64_t probeCacheHits() const = 0;
+};
+
 /* GpuScheduler with (a) a program dump of what the reference compiles for the
  * GROUP BY + scan and (b) the CPU PartialGroupByExpression of a data node
  * (server/sql/scheduler.cc:79-115) when asked for */
-class ProbeScheduler : public GpuScheduler {
+class ProbeScheduler : public GpuScheduler, public DecisionSource {
 public:
   ProbeScheduler(std::shared_ptr<GpuTableRegistry> t, GpuSchedulerOptions o, bool cpu_partial)
       : GpuScheduler(t, o), cpu_partial_(cpu_partial) {}
+  const std::vector<GpuLowering::Decision>& probeDecisions() const override { return decisions(); }
+  void probeClear() override { clearDecisions(); }
+  uint64_t probeCacheHits() const override { return queryCacheHits(); }
 
 protected:
   ScopedPtr<csql::TableExpression> buildGroupByExpression(
@@ -325,6 +346,32 @@ protected:
   bool cpu_partial_;
 };
 
+/* The object evqld would hand to Runtime::setScheduler: the GPU mix-in over
+ * eventql::Scheduler (server/sql/scheduler.h:37).  The probe plays the data node of a
+ * distributed GROUP BY: the coordinator's eventql::Scheduler::buildPipelineGroupByExpression
+ * ships GroupByNode copies with setIsPartialAggreagtion(true) (server/sql/scheduler.cc:
+ * 146-158) -- the coordinator half itself needs a running cluster (PartitionMap, metadata
+ * client, RPC) and is not reachable from a standalone csql::Runtime. */
+class ProbeEvqldScheduler : public GpuSchedulerT<eventql::Scheduler>, public DecisionSource {
+public:
+  ProbeEvqldScheduler(std::shared_ptr<GpuTableRegistry> t, GpuSchedulerOptions o,
+                      eventql::ProcessConfig* config)
+      : GpuSchedulerT<eventql::Scheduler>(t, o, config, (eventql::PartitionMap*) nullptr,
+                                          (eventql::ConfigDirectory*) nullptr,
+                                          (eventql::InternalAuth*) nullptr) {}
+  const std::vector<GpuLowering::Decision>& probeDecisions() const override { return decisions(); }
+  void probeClear() override { clearDecisions(); }
+  uint64_t probeCacheHits() const override { return queryCacheHits(); }
+
+protected:
+  ScopedPtr<csql::TableExpression> buildGroupByExpression(
+      csql::Transaction* txn, csql::ExecutionContext* ctx,
+      RefPtr<csql::GroupByNode> node) override {
+    node->setIsPartialAggreagtion(true);
+    return GpuSchedulerT<eventql::Scheduler>::buildGroupByExpression(txn, ctx, node);
+  }
+};
+
 struct Probe {
   RefPtr<csql::Runtime> runtime;
   std::shared_ptr<GpuTableRegistry> registry;
@@ -336,7 +383,8 @@ struct Probe {
   std::unique_ptr<eventql::FileTracker> file_tracker;
   eventql::DatabaseContext dbctx{};
   std::vector<Tbl> tables;
-  ProbeScheduler* scheduler = nullptr; /* owned by the runtime */
+  DecisionSource* scheduler = nullptr; /* owned by the runtime */
+  RefPtr<eventql::ProcessConfig> evqld_config;
 
   Probe() {
     runtime = csql::Runtime::getDefaultRuntime();
@@ -350,14 +398,29 @@ struct Probe {
     o.partial = g_state.partial;
     o.strict = g_state.strict;
     bool cpu_partial = g_state.partial && g_state.mode == "cpu";
-    scheduler = new ProbeScheduler(registry, o, cpu_partial);
-    runtime->setScheduler(ScopedPtr<csql::Scheduler>(scheduler));
+    if (g_state.mode == "evqld") {
+      if (!evqld_config.get()) {
+        eventql::ProcessConfigBuilder b;
+        b.setProperty("server.query_max_concurrent_shards", "8");
+        b.setProperty("server.query_max_concurrent_shards_per_host", "6");
+        b.setProperty("server.query_failed_shard_policy", "tolerate");
+        evqld_config = b.getConfig();
+      }
+      o.lower_group_by = true;
+      auto s = new ProbeEvqldScheduler(registry, o, evqld_config.get());
+      scheduler = s;
+      runtime->setScheduler(ScopedPtr<csql::Scheduler>(s));
+      return;
+    }
+    auto s = new ProbeScheduler(registry, o, cpu_partial);
+    scheduler = s;
+    runtime->setScheduler(ScopedPtr<csql::Scheduler>(s));
   }
 
   std::string runOnce(const std::string& sql, bool want_rows, double* seconds) {
     std::ostringstream o;
     g_state.programs_json.clear();
-    if (scheduler) scheduler->clearDecisions();
+    if (scheduler) scheduler->probeClear();
     auto t0 = std::chrono::steady_clock::now();
     o << "{\"sql\":" << jsonString(sql) << ",\"mode\":" << jsonString(g_state.mode)
       << ",\"partial\":" << (g_state.partial ? "true" : "false");
@@ -416,16 +479,16 @@ struct Probe {
     if (g_state.dump && !g_state.programs_json.empty()) {
       o << ",\"programs\":" << g_state.programs_json;
     }
-    if (scheduler && !scheduler->decisions().empty()) {
+    if (scheduler && !scheduler->probeDecisions().empty()) {
       o << ",\"decisions\":[";
       bool first = true;
-      for (const auto& d : scheduler->decisions()) {
+      for (const auto& d : scheduler->probeDecisions()) {
         o << (first ? "" : ",") << "{\"node\":" << jsonString(d.node) << ",\"lowered\":"
           << (d.lowered ? "true" : "false") << ",\"reason\":" << jsonString(d.reason) << "}";
         first = false;
       }
       o << "]";
-      o << ",\"query_cache_hits\":" << scheduler->queryCacheHits();
+      o << ",\"query_cache_hits\":" << scheduler->probeCacheHits();
     }
     return o.str();
   }

@@ -261,3 +261,63 @@ def test_rccl_transport_single_rank(ctx):
     finally:
         x.close()
         t.close()
+
+
+@pytest.mark.parametrize("name", ["u64-key", "string-key-partitioned-path", "distinct-string-key",
+                                  "two-keys", "high-card-leb-key"])
+def test_eight_ranks_on_one_gpu(name):
+    """the rank count of the target node (8 x MI355X): eight hub ranks as threads on the
+    one GPU of this box, both modes -- config 3's shape (u64 key, float sums), config 4's
+    (high cardinality, the partitioned path), config 4s' (string keys: first rows and string
+    heaps travel), count_distinct pair sets, two-column keys"""
+    kw = dict(PLANS[name])
+    kc = kw.pop("key_cols", 1)
+    parts = [partition(900 + r, 12_000 + 1000 * r) for r in range(8)]
+    exp = O.oracle_run(image_of(parts), Plan(S, **kw))
+    res = run_ranks(8, parts, kw, K.EXCHANGE_BY_OWNER)
+    union = [row for rows, _, _ in res for row in rows]
+    assert len(union) == exp.nrows
+    T.compare_results(union, exp.rows(), exp.types, key_cols=kc, rel=1e-9)
+    assert sum(1 for rows, _, _ in res if rows) == 8, "a rank owns nothing"
+    res = run_ranks(8, parts, kw, K.EXCHANGE_GATHER_ALL)
+    canon = [sorted(map(repr, r[0])) for r in res]
+    assert all(c == canon[0] for c in canon[1:])
+    T.compare_results(res[7][0], exp.rows(), exp.types, key_cols=kc, rel=1e-9)
+
+
+def test_eight_ranks_exact_float_sums():
+    """EVQL_FLOAT_SUM_EXACT with one bound on every rank: the merged sums do not depend on
+    how the rows are split over 8 ranks (bit-identical to the 1-rank result)"""
+    parts = [partition(950 + r, 9_000) for r in range(8)]
+    kw = dict(select=[col("k"), sum_(col("v")), count(1)], group_by=[col("k")],
+              float_sum_mode=K.FLOAT_SUM_EXACT, float_sum_bound=1024.0)
+    one = run_ranks(1, [dict((n, np.concatenate([p[n] for p in parts]) if n not in ("s", "ns")
+                              else [x for p in parts for x in p[n]]) for n in parts[0])],
+                    kw, K.EXCHANGE_GATHER_ALL)
+    eight = run_ranks(8, parts, kw, K.EXCHANGE_GATHER_ALL)
+    base = sorted(map(repr, one[0][0]))
+    assert all(sorted(map(repr, r[0])) == base for r in eight)
+
+
+def test_wide_first_row_plan_is_refused_before_anything_is_written(ctx):
+    """the merged slot of a plan that reads first-row values is W + ncols + 1
+    words; beyond the 33 the merge kernels take, the exchange answers EVQL_ENOTSUP -- before
+    it fills any fixed-size array"""
+    parts = [partition(77, 5_000)]
+    t = ctx.open_image(image_of(parts))
+    aggs = [min_(col("a") + i) for i in range(13)]           # 26 state words
+    kw = dict(select=[col("k"), col("s"), col("ns"), col("u"), col("v"), col("a")] + aggs,
+              group_by=[col("k")])
+    q = t.query(Plan(S, **kw))
+    hub = E.Hub(1)
+    x = E.Exchange.hub(ctx, hub, 0)
+    q.execute()
+    with pytest.raises(E.EvqlError) as ei:
+        q.exchange(x, K.EXCHANGE_GATHER_ALL)
+    assert ei.value.code == K.EVQL_ENOTSUP and "words per merged group" in ei.value.msg
+    # the un-exchanged result is still there
+    assert q.fetch_all().nrows == len(set(parts[0]["k"].tolist()))
+    q.close()
+    x.close()
+    hub.close()
+    t.close()

@@ -1203,6 +1203,107 @@ def test_plan_without_a_hint_finds_the_partitioned_path_by_itself(ctx):
         t.close()
 
 
+def test_hint_less_plan_over_keys_that_follow_the_row_order(ctx):
+    """a time-ordered table: the key grows with the row number, so a prefix of the scan
+    holds a handful of groups while the table has 90,000.  The probe samples row ranges
+    spread over the whole scan range; a wrong estimate would still give the
+    right rows (TABLE_FULL / DENSE_FULL re-runs), only slower"""
+    n = 9_000_000
+    i = np.arange(n, dtype=np.uint64)
+    w = E.Writer([dict(name="ts", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+                  dict(name="a", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN)])
+    w.put("ts", i // np.uint64(100))
+    w.put("a", (i * np.uint64(2654435761)) % np.uint64(65536))
+    w.commit(n)
+    img = w.image()
+    w.close()
+    t = ctx.open_image(img)
+    try:
+        S = dict(ts=K.T_UINT64, a=K.T_UINT64)
+        plan = Plan(S, select=[col("ts"), count(1), sum_(col("a"))], group_by=[col("ts")])
+        q = t.query(plan)
+        got = q.run()
+        st = q.stats()
+        # (within the probe's sample every key is seen ~100 times in 16 runs of consecutive
+        # rows: the occupancy estimate sees 16 * 164 distinct keys among 262,144 rows and
+        # cannot know better than "at least that many"; what matters is that it is no
+        # longer the prefix's 2,622)
+        assert st["estimated_groups"] >= 2_600, st
+        assert got.nrows == 90_000
+        rows = sorted(got.rows())
+        assert [r[0] for r in rows] == list(range(90_000))
+        assert all(r[1] == 100 for r in rows)
+        a = (i * np.uint64(2654435761)) % np.uint64(65536)
+        assert [r[2] for r in rows[:1000]] == a[:100_000].reshape(1000, 100).sum(axis=1).tolist()
+        q.close()
+    finally:
+        t.close()
+
+
+def test_exact_float_sums_refuse_mismatched_quanta(ctx):
+    """with float_sum_bound = 0 every partition derives its quantum from its
+    OWN maxima.  Two partitions whose maxima lie on either side of a power of two must
+    not have their integer state words added: the exchange (and import_groups) answers
+    EVQL_EARG instead of a silently wrong 'exact' sum; with one explicit bound the same
+    exchange works"""
+    import threading
+
+    def table(scale):
+        n = 50_000
+        w = E.Writer([dict(name="k", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+                      dict(name="v", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754)])
+        w.put("k", np.arange(n, dtype=np.uint64) % np.uint64(7))
+        w.put("v", (np.arange(n, dtype=np.float64) % 1000.0) * scale)
+        w.commit(n)
+        img = w.image()
+        w.close()
+        return img
+    imgs = [table(1.0), table(5.0)]  # maxima 999 and 4995: different binades
+    S = dict(k=K.T_UINT64, v=K.T_FLOAT64)
+    kw = dict(select=[col("k"), sum_(col("v"))], group_by=[col("k")])
+
+    def run(bound):
+        hub = E.Hub(2)
+        out = [None, None]
+
+        def work(r):
+            cx = E.Context(0)
+            tt = cx.open_image(imgs[r])
+            qq = tt.query(Plan(S, float_sum_mode=K.FLOAT_SUM_EXACT, float_sum_bound=bound, **kw))
+            x = E.Exchange.hub(cx, hub, r)
+            qq.execute()
+            try:
+                qq.exchange(x, K.EXCHANGE_GATHER_ALL)
+                out[r] = sorted(qq.fetch_all().rows())
+            except E.EvqlError as e:
+                out[r] = e
+            qq.close(); x.close(); tt.close(); cx.close()
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        [x.start() for x in th]
+        [x.join(timeout=300) for x in th]
+        hub.close()
+        return out
+    bad = run(0.0)
+    assert all(isinstance(o, E.EvqlError) and o.code == K.EVQL_EARG and "quant" in o.msg for o in bad), bad
+    good = run(8192.0)
+    exp = {}
+    for r, scale in enumerate((1.0, 5.0)):
+        for i in range(50_000):
+            exp[i % 7] = exp.get(i % 7, 0.0) + (i % 1000) * scale
+    assert good[0] == good[1] == sorted(exp.items())
+    # export / import: only with an explicit bound
+    import torch
+    t = ctx.open_image(imgs[0])
+    q = t.query(Plan(S, float_sum_mode=K.FLOAT_SUM_EXACT, **kw))
+    q.execute()
+    buf = torch.zeros(1 << 12, dtype=torch.int64, device="cuda")
+    with pytest.raises(E.EvqlError) as ei:
+        q.export_groups(buf.data_ptr(), 64)
+    assert ei.value.code == K.EVQL_EARG
+    q.close()
+    t.close()
+
+
 def test_exact_float_sums(ctx, mixed):
     """EVQL_FLOAT_SUM_EXACT: every value is rounded once to a multiple of a power of two
     and the multiples are added as integers -- bit-stable from run to run and for any

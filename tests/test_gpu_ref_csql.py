@@ -27,7 +27,7 @@ import refcases
 import sqlgen
 import tables as T
 from test_ref_csql_cpu import (SUITES, load, fixture_case, case_plan, check_result,
-                               check_partial, all_lowerable, _param_cases)
+                               check_partial, all_lowerable, _param_cases, run_evqld_mode)
 
 pytestmark = pytest.mark.gpu
 
@@ -251,3 +251,13 @@ def test_order_by_and_limit_are_fused_into_the_operator():
             assert d.get("orderby") is True, (q, g["decisions"])
             if "limit" in q:
                 assert d.get("limit") is True, (q, g["decisions"])
+
+
+@pytest.mark.skipif(not os.path.exists(PROBE), reason="oracle/_ref/csql_probe not built "
+                    "(needs /root/reference at build time)")
+@pytest.mark.parametrize("suite", ["survey", "mixed"])
+def test_evqld_scheduler_mixin(suite):
+    """GpuSchedulerT<eventql::Scheduler> -- the object evqld installs -- serving the data
+    node half of a distributed GROUP BY: PartialGroupByExpression's GPU twin for the plans
+    it lowers, eventql::Scheduler's CPU operator for the rest, identical bytes"""
+    run_evqld_mode(suite, 0.85)
