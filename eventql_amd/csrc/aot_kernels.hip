@@ -1128,6 +1128,98 @@ __global__ void __launch_bounds__(kBlock) k_lsm_filter(LsmArgs a) {
   }
 }
 
+// ---- string dictionaries (string_dict.cc) ---------------------------------------------
+// records of the dictionary's GROUP BY over the column's 64-bit string hash:
+// [kind, hash, first row, count]; record i becomes code i
+__global__ void __launch_bounds__(kBlock) k_dict_insert(DictArgs a) {
+  const u64 mask = a.cap - 1;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < a.ncodes;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = (const u64*) a.records + i * 4;
+    const u64 kind = rec[0], h = rec[1];
+    a.entries[i * 3] = kind == 1 ? EVQL_EMPTY : h;
+    a.entries[i * 3 + 1] = rec[2];
+    a.entries[i * 3 + 2] = kind == 2 ? 1ull : 0ull;
+    if (kind == 1) { a.special[0] = i; continue; }  // the hash value 2^64-1
+    if (kind == 2) { a.special[1] = i; continue; }  // the NULL key
+    u64 s = evql_mix64(h) & mask;
+    for (u64 probe = 0; probe < a.cap; ++probe, s = (s + 1) & mask) {
+      // (hashes are distinct: one record per group)
+      if (atomicCAS((unsigned long long*) &a.tab[s], EVQL_EMPTY, h) == EVQL_EMPTY) {
+        a.tab[a.cap + s] = i;
+        break;
+      }
+    }
+  }
+}
+
+// code of every row + the proof that the dictionary is EXACT: the bytes of the row's
+// string equal the bytes of its code's representative (the group's first row)
+__global__ void __launch_bounds__(kBlock) k_dict_assign(DictArgs a) {
+  const u64 mask = a.cap - 1;
+  for (u64 r = (u64) blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows;
+       r += (u64) gridDim.x * blockDim.x) {
+    u64 code = EVQL_EMPTY;
+    const bool null = a.tags && (a.tags[r] & 1);
+    const u64 h = a.hashes[r];
+    if (null) {
+      code = a.special[1];
+    } else if (h == EVQL_EMPTY) {
+      code = a.special[0];
+    } else {
+      u64 s = evql_mix64(h) & mask;
+      for (u64 probe = 0; probe < a.cap; ++probe, s = (s + 1) & mask) {
+        const u64 k = a.tab[s];
+        if (k == EVQL_EMPTY) break;
+        if (k == h) {
+          code = a.tab[a.cap + s];
+          break;
+        }
+      }
+    }
+    if (code >= a.ncodes) {
+      atomicOr(&a.status[0], 1u);
+      continue;
+    }
+    if (!null) {
+      const u64 rep = a.entries[code * 3 + 1];
+      if (rep != r) {
+        const u64 sp = a.strpos[r], sq = a.strpos[rep];
+        bool same = (sp >> 40) == (sq >> 40) && (a.entries[code * 3 + 2] & 1) == 0;
+        const u32 len = (u32) (sp >> 40);
+        const u64 o1 = sp & kStrOffMask, o2 = sq & kStrOffMask;
+        for (u32 k = 0; same && k < len; ++k) {
+          same = vbyte_fwd(a.image, (const u64*) a.pages, o1 + k) ==
+                 vbyte_fwd(a.image, (const u64*) a.pages, o2 + k);
+        }
+        if (!same) atomicOr(&a.status[0], 2u);  // two strings, one 64-bit hash
+      }
+    }
+    a.codes[r] = (u32) code;
+  }
+}
+
+// group records keyed by dictionary code [kind, code, states...] -> the records of the
+// same plan with a hashed string key [0, ident, ident 2, first row, states...]
+// (evql_ident_add: the words the generated row function computes for that string)
+__global__ void __launch_bounds__(kBlock) k_dict_records(const u64* in, u64 n, u32 in_words,
+                                                         const u64* entries, u64* out) {
+  const u32 ow = in_words + 2;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = in + i * in_words;
+    u64* o = out + i * ow;
+    const u64* e = entries + rec[1] * 3;
+    u64 ident = EVQL_IDENT_SEED1, ident2 = EVQL_IDENT_SEED2;
+    evql_ident_add(ident, ident2, e[0], (u32) e[2]);
+    o[0] = 0;
+    o[1] = evql_ident_word(ident);
+    o[2] = evql_ident_word(ident2);
+    o[3] = e[1];
+    for (u32 w = 2; w < in_words; ++w) o[w + 2] = rec[w];
+  }
+}
+
 // ---- synthetic table -----------------------------------------------------------------
 // one thread generates 128 consecutive rows (= one bit-packed block)
 __global__ void __launch_bounds__(kBlock) k_synth(const SynthArgs* ap, u64 nchunks) {
@@ -1818,6 +1910,26 @@ hipError_t launch_lsm_insert(const LsmArgs& a, hipStream_t s) {
 hipError_t launch_lsm_filter(const LsmArgs& a, hipStream_t s) {
   if (a.nrows == 0) return hipSuccess;
   hipLaunchKernelGGL(k_lsm_filter, dim3(grid_for(a.nrows)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_dict_insert(const DictArgs& a, hipStream_t s) {
+  if (a.ncodes == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(a.ncodes)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_dict_assign(const DictArgs& a, hipStream_t s) {
+  if (a.nrows == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dict_assign, dim3(grid_for(a.nrows)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_dict_records(const uint64_t* in, uint64_t n, uint32_t in_words,
+                               const uint64_t* entries, uint64_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dict_records, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) in, (u64) n,
+                     in_words, (const u64*) entries, (u64*) out);
   return hipGetLastError();
 }
 

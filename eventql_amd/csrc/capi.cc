@@ -718,7 +718,8 @@ int evql_query_next_batch(evql_query_t* q, size_t max_rows, evql_column_buf_t* c
 int evql_query_stats(const evql_query_t* q, evql_query_stats_t* out) {
   *out = q->stats;
   uint64_t bytes = 0;
-  for (const auto& c : q->within_record ? q->wr_cols : q->kp.cols) {
+  // (a dictionary-coded key counts as the string column it stands for)
+  for (const auto& c : q->within_record ? q->wr_cols : q->rplan().cols) {
     bytes += q->table->payload_bytes[c.layout_index];
   }
   // scaled to the scanned row range; + result bytes (key + 8 B per aggregate)
@@ -727,7 +728,7 @@ int evql_query_stats(const evql_query_t* q, evql_query_stats_t* out) {
     bytes = uint64_t(double(bytes) * double(q->stats.rows_scanned) / double(nrows));
   }
   for (const evql_query* part : q->chain) {  // (chain_merge summed the row counters)
-    for (const auto& c : part->kp.cols) bytes += part->table->payload_bytes[c.layout_index];
+    for (const auto& c : part->rplan().cols) bytes += part->table->payload_bytes[c.layout_index];
   }
   bytes += q->stats.num_groups * 8 * (1 + q->kp.aggs.size());
   out->algorithmic_bytes = bytes;
@@ -738,12 +739,13 @@ const char* evql_query_kernel_source(const evql_query_t* q) { return q->source.c
 
 // ---- partial aggregates ---------------------------------------------------------------
 uint32_t evql_query_record_words(const evql_query_t* q) {
-  return uint32_t(q->kp.words_per_slot()) + 1;
+  return uint32_t(q->rplan().words_per_slot()) + 1;
 }
 
 int evql_query_partial_view(evql_query_t* q, evql_partial_view_t* out) {
   if (!q || !out) return fail(EVQL_EARG, "null argument");
   if (q->merged) return fail(EVQL_EARG, "the query's groups were merged (exchange / chain): emit them with next_batch");
+  if (q->dict_key) return fail(EVQL_ENOTSUP, "plan groups by dictionary codes: merge it with evql_query_exchange");
   {
     Status st = query_dense_into_table(q);
     if (!st.ok()) return ret(st);
@@ -765,7 +767,7 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
     return fail(EVQL_EARG, "exact float sums travel between partitions only with an explicit float_sum_bound");
   }
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
-  if (q->kp.need_first_row) {
+  if (q->rplan().need_first_row) {
     // a first-row index means something only inside the table that produced it:
     // the key / select values of such plans travel inside the records of
     // evql_query_exchange (exchange.cc, k_resolve_records)
@@ -805,7 +807,7 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
     return fail(EVQL_EARG, "exact float sums travel between partitions only with an explicit float_sum_bound");
   }
   if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
-  if (q->kp.need_first_row) {
+  if (q->rplan().need_first_row) {
     return fail(EVQL_ENOTSUP, "plan reads first-row values: merge it with evql_query_exchange");
   }
   hipStream_t s = q->ctx->stream;
@@ -846,6 +848,7 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
 
 int evql_query_reset(evql_query_t* q) {
   API_TRY
+  if (q->dict_key) return fail(EVQL_ENOTSUP, "plan groups by dictionary codes: not a merge target");
   return ret(query_reset(q));
   API_CATCH
 }

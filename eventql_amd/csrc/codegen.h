@@ -22,6 +22,7 @@ struct ColAccess {
   bool string_hash = false;   // STRING column materialised as hash64
   bool string_bytes = false;  // ... and compared bytewise on the device (strpos array)
   bool packed = false;        // BITPACKED over the runtime's re-encoded copy (LEB128)
+  bool dict_code = false;     // PLAIN32 over the table's dictionary codes of a STRING column
   int layout_index = -1;      // index into TableLayout::columns
 };
 

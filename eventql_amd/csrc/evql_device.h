@@ -99,6 +99,20 @@ __device__ __forceinline__ u64 evql_hash_combine(u64 h, u64 v) {
   return evql_mix64(h ^ (v + 0x9e3779b97f4a7c15ULL + (h << 6) + (h >> 2)));
 }
 
+// identity of a hashed group key (several keys / strings): two 64-bit words folded over
+// the key values in GROUP BY order; value bits `v` (strings: their 64-bit hash), NULL
+// tag `g`.  Shared by the generated row function and the conversion of dictionary-coded
+// group records into this form (aot_kernels.hip k_dict_records).
+#define EVQL_IDENT_SEED1 0x243f6a8885a308d3ull
+#define EVQL_IDENT_SEED2 0x13198a2e03707344ull
+__device__ __forceinline__ void evql_ident_add(u64& ident, u64& ident2, u64 v, u32 g) {
+  ident = evql_hash_combine(ident, v);
+  ident = evql_hash_combine(ident, (u64) (g & 1u));
+  ident2 = evql_mix64(ident2 * 0x9e3779b97f4a7c15ull + v) ^ (u64) (g & 1u);
+}
+// (the all-ones pattern marks a free word)
+__device__ __forceinline__ u64 evql_ident_word(u64 x) { return x == ~0ull ? ~0ull - 1 : x; }
+
 // ---------------------------------------------------------------------------
 // column page access.  Pages are only guaranteed 4-byte aligned in the file
 // (a bit-packed page is 4 + 16*b*1024 bytes), so vector loads are declared

@@ -313,7 +313,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   evql_ctx* ctx = q->ctx;
   evql_table* t = q->table;
   hipStream_t s = ctx->stream;
-  const KernelPlan& kp = q->kp;
+  const KernelPlan& kp = q->rplan();
   const int N = x->nranks;
   if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
   if (kp.n_distinct && q->group_mode == EVQL_MODE_PARTIAL) {
@@ -357,8 +357,11 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   WsBuf<uint64_t> d_rec(x, 0);
   HIP_TRY(d_rec.alloc(std::max<uint64_t>(n, 1) * rw_in * 8));
   {
-    const uint64_t nd = std::min(q->dense_n, n);
-    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
+    RecordsView view;
+    Status stv = query_records_view(q, &view);
+    if (!stv.ok()) return stv;
+    const uint64_t nd = view.nd;
+    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, view.dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
     if (n > nd) {
       uint64_t* d_cnt = q->d_counters + 6;
       HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
@@ -679,7 +682,7 @@ namespace evql {
 Status chain_merge(evql_query* head) {
   evql_ctx* ctx = head->ctx;
   hipStream_t s = ctx->stream;
-  const KernelPlan& kp = head->kp;
+  const KernelPlan& kp = head->rplan();
   std::vector<evql_query*> parts;
   parts.push_back(head);
   for (evql_query* c : head->chain) parts.push_back(c);
@@ -697,8 +700,10 @@ Status chain_merge(evql_query* head) {
   for (evql_query* p : parts) {
     // (same plan everywhere: the slot layouts agree; a different KEY mode or word count
     // would mean different plans)
-    if (uint32_t(p->kp.words_per_slot()) != W || p->kp.cols.size() != nc ||
-        p->kp.key_mode != kp.key_mode || p->kp.need_first_row != kp.need_first_row) {
+    // (a table whose string key has no usable dictionary keeps the hashed plan; its
+    // records have the same rplan() layout as the coded tables')
+    if (uint32_t(p->rplan().words_per_slot()) != W || p->rplan().cols.size() != nc ||
+        p->rplan().key_mode != kp.key_mode || p->rplan().need_first_row != kp.need_first_row) {
       return Status::error(EVQL_ERUNTIME, "chain: the tables' plans disagree");
     }
     if (!p->executed) return Status::error(EVQL_EARG, "execute() was not called");
@@ -768,8 +773,11 @@ Status chain_merge(evql_query* head) {
     kernel_ms += q->stats.kernel_ms;
     const uint64_t n = q->ngroups;
     if (n == 0) continue;
-    const uint64_t nd = std::min(q->dense_n, n);
-    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
+    RecordsView view;
+    Status stv = query_records_view(q, &view);
+    if (!stv.ok()) return stv;
+    const uint64_t nd = view.nd;
+    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, view.dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
     if (n > nd) {
       uint64_t* d_cnt = q->d_counters + 6;
       HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
@@ -784,7 +792,7 @@ Status chain_merge(evql_query* head) {
     std::vector<uint32_t> str_cols;
     uint64_t str_mask = 0;
     for (uint32_t c = 0; c < nc; ++c) {
-      const ColAccess& ca = q->kp.cols[c];
+      const ColAccess& ca = q->rplan().cols[c];
       rc[c] = RtColumn{};
       rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
       rc[c].mode = ca.mode;
@@ -830,7 +838,7 @@ Status chain_merge(evql_query* head) {
       for (size_t k = 0; k < str_cols.size(); ++k) {
         wa.word[k] = rw_in + str_cols[k];
         wa.col[k] = str_cols[k];
-        wa.pages[k] = t->d_pages[q->kp.cols[str_cols[k]].layout_index][0];
+        wa.pages[k] = t->d_pages[q->rplan().cols[str_cols[k]].layout_index][0];
       }
       HIP_TRY(d_sizes.alloc((n + 4) * 8));
       wa.sizes = d_sizes;

@@ -506,6 +506,9 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
   q->select_agg_index.assign(plan->n_select, -1);
   q->select_passthrough.assign(plan->n_select, false);
   kp.need_first_row = false;
+  // does anything but the group key itself read the group's first row?  (a string key that
+  // is only grouped by and selected can be coded through the table's dictionary)
+  bool first_row_beyond_key = false;
   for (uint32_t i = 0; i < plan->n_select; ++i) {
     LoweredProgram& lp = q->select[i];
     err = lower_program(plan->select_exprs[i], &lp, &u);
@@ -582,7 +585,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
       kp.aggs.push_back(a);
       // post-aggregate arithmetic that also reads group-level inputs needs the
       // group's first row
-      if (has_input(lp.call)) kp.need_first_row = true;
+      if (has_input(lp.call)) {
+        kp.need_first_row = true;
+        first_row_beyond_key = true;
+      }
     } else {
       if (has_agg_get(lp.call)) return Status::error(EVQL_EARG, "malformed aggregate program");
       ExprPtr e = inline_inputs(lp.call, scan_out, &err);
@@ -594,6 +600,7 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
         // constant expression: no row needed
       } else {
         kp.need_first_row = true;
+        if (!(kp.group.size() == 1 && expr_equal(e, kp.group[0]))) first_row_beyond_key = true;
       }
     }
   }
@@ -608,6 +615,26 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
   }
 
   kp.has_row_filter = plan->row_filter_bits != nullptr;
+
+  // One STRING key that is only grouped by (and selected as it is): the runtime may run
+  // the plan on the column's dictionary codes instead of its hashes (string_dict.cc,
+  // query_prepare).  Not when WHERE or an aggregate reads the column too (they need the
+  // bytes / hashes anyway), nor with count_distinct (its pair sets are keyed by the
+  // identity words).
+  q->dict_candidate = -1;
+  if (!nested && kp.key_mode == KEY_HASHED && kp.group.size() == 1 && kp.n_distinct == 0 &&
+      !first_row_beyond_key && kp.group[0]->kind == Expr::INPUT &&
+      kp.group[0]->input < kp.cols.size() && kp.cols[kp.group[0]->input].string_hash) {
+    const uint32_t ki = kp.group[0]->input;
+    std::vector<uint32_t> used;
+    if (kp.where) expr_inputs(kp.where, &used);
+    for (const auto& a : kp.aggs) {
+      if (a.arg) expr_inputs(a.arg, &used);
+    }
+    bool elsewhere = false;
+    for (uint32_t u2 : used) elsewhere = elsewhere || u2 == ki;
+    if (!elsewhere) q->dict_candidate = int(ki);
+  }
 
   choose_launch_shape(&kp, plan->groups_hint);
   return Status();

@@ -288,6 +288,7 @@ evql_query::~evql_query() {
   if (d_part_cursors) hipFree(d_part_cursors);
   if (d_dense) hipFree(d_dense);
   if (d_mtab) hipFree(d_mtab);
+  if (d_conv) hipFree(d_conv);
   for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
@@ -1152,6 +1153,10 @@ static Status column_abs_max(evql_query* q, size_t i, double* out) {
     *out = std::numeric_limits<double>::infinity();
     return Status();
   }
+  if (c.dict_code) {  // dense codes 0 .. n_codes - 1
+    *out = double(t->dicts[c.name].n_codes - 1);
+    return Status();
+  }
   const bool is_float = c.stype == EVQL_T_FLOAT64 && !c.from_uint_to_float;
   const std::string key = c.name + (is_float ? "#f" : "#u");
   if (!q->nested) {
@@ -1347,6 +1352,35 @@ Status query_prepare(evql_query* q) {
       }
     }
   }
+  if (q->dict_candidate >= 0 && !q->nested) {
+    // a STRING key with a usable dictionary: the kernels group by its 32-bit codes.
+    // (Here, behind the loop above: the record-level copy of the plan must know the
+    // resolved access modes of the other columns -- first-row gathers read them.)
+    KernelPlan& kp = q->kp;
+    const int ki = q->dict_candidate;
+    StringDict* dict = nullptr;
+    Status std_ = table_string_dict(t, kp.cols[ki].layout_index, &dict);
+    if (!std_.ok()) return std_;
+    if (dict->usable) {
+      q->rkp = kp;  // what the group records look like outside the scan
+      ColAccess code = kp.cols[ki];
+      code.stype = EVQL_T_UINT64;
+      code.mode = ColAccess::PLAIN32;
+      code.has_tags = false;
+      code.string_hash = code.string_bytes = false;
+      code.dict_code = true;
+      kp.cols[ki] = code;
+      auto in = std::make_shared<Expr>();
+      in->kind = Expr::INPUT;
+      in->type = EVQL_T_UINT64;
+      in->input = uint32_t(ki);
+      kp.group[0] = in;
+      kp.key_mode = KEY_EXACT;
+      kp.need_first_row = false;
+      q->dict_key = true;
+      choose_launch_shape(&kp, q->groups_hint);
+    }
+  }
   if (repacked && !q->kp.partitioned) {
     // the access modes changed: block / unroll / LDS table are chosen again
     choose_launch_shape(&q->kp, q->groups_hint);
@@ -1535,7 +1569,11 @@ static void fill_host_args(evql_query* q, HostArgs* ap) {
       a.col[i].pages = t->d_pages[c.layout_index][0];
       a.col[i].npages = t->layout.columns[c.layout_index].data_pages.size();
     }
-    if (c.packed && q->nested) {
+    if (c.dict_code) {
+      const StringDict& d = t->dicts[c.name];
+      a.col[i].pages = d.d_code_pages;
+      a.col[i].base = reinterpret_cast<const uint8_t*>(d.d_codes);
+    } else if (c.packed && q->nested) {
       a.col[i].pages = q->nested_packed[i].pages;
       a.col[i].base = q->nested_packed[i].base;
     } else if (c.packed) {
@@ -1653,6 +1691,7 @@ Status query_launch(evql_query* q) {
   }
   q->probed = true;
   q->merged = false;
+  q->conv_valid = false;
   const KernelPlan& kp = q->kp;
   hipStream_t s = ctx->stream;
   if (!q->d_gtab) {
@@ -1809,6 +1848,47 @@ Status query_launch(evql_query* q) {
 }
 
 static Status fetch_results(evql_query* q);
+
+// The groups of `q` as dense records of rplan()'s layout.  Plans that ran on dictionary
+// codes are translated here, once per execute and only when somebody asks: code ->
+// the hashed identity words of the string + its first row (k_dict_records).
+Status query_records_view(evql_query* q, RecordsView* v) {
+  if (!q->dict_key) {
+    v->dense = q->d_dense;
+    v->nd = std::min(q->dense_n, q->ngroups);
+    return Status();
+  }
+  hipStream_t s = q->ctx->stream;
+  const uint64_t n = q->ngroups;
+  if (!q->conv_valid && n) {
+    const uint32_t in_words = uint32_t(q->kp.words_per_slot()) + 1;
+    const uint64_t nd = std::min(q->dense_n, n);
+    DevBuf<uint64_t> tmp;
+    const uint64_t* src = q->d_dense;
+    if (n > nd) {  // groups of overflowed buckets / of the LDS path sit in the HBM table
+      HIP_TRY(tmp.alloc(n * in_words * 8));
+      if (nd) HIP_TRY(hipMemcpyAsync(tmp, q->d_dense, nd * in_words * 8, hipMemcpyDeviceToDevice, s));
+      uint64_t* d_cnt = q->d_counters + 6;
+      HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, in_words - 1,
+                                   tmp.p + nd * in_words, n - nd, d_cnt, s));
+      src = tmp;
+    }
+    if (q->conv_cap < n) {
+      if (q->d_conv) hipFree(q->d_conv);
+      q->d_conv = nullptr;
+      q->conv_cap = n + n / 8 + 1024;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_conv), q->conv_cap * uint64_t(in_words + 2) * 8));
+    }
+    const StringDict& d = q->table->dicts[q->rkp.cols[q->dict_candidate].name];
+    HIP_TRY(launch_dict_records(src, n, in_words, d.d_entries, q->d_conv, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (tmp lives until here)
+    q->conv_valid = true;
+  }
+  v->dense = q->d_conv;
+  v->nd = n;
+  return Status();
+}
 
 Status query_finish(evql_query* q) {
   if (!q->launched) return Status::error(EVQL_EARG, "query was not launched");
@@ -2017,7 +2097,7 @@ Status query_reset(evql_query* q) {
 static Status fetch_results(evql_query* q) {
   evql_ctx* ctx = q->ctx;
   evql_table* t = q->table;
-  const KernelPlan& kp = q->kp;
+  const KernelPlan& kp = q->rplan();
   hipStream_t s = ctx->stream;
   // after an exchange the groups live in the merged table (wider slots)
   const bool merged = q->merged;
@@ -2026,7 +2106,12 @@ static Status fetch_results(evql_query* q) {
   const uint64_t gcap = merged ? q->mcap : q->gcap;
   const uint64_t stride = gcap + 8;
   const uint64_t maxrec = gcap + 2;
-  const uint64_t dense_n = merged ? 0 : q->dense_n;
+  RecordsView view;
+  if (!merged) {
+    Status stv = query_records_view(q, &view);
+    if (!stv.ok()) return stv;
+  }
+  const uint64_t dense_n = merged ? 0 : view.nd;
   uint64_t* d_rec = nullptr;
   uint64_t* d_cnt = q->d_counters + 5;
   // the record buffer is sized by the number of groups (counted by finish /
@@ -2049,7 +2134,7 @@ static Status fetch_results(evql_query* q) {
     // dense records of the partitioned path first, the table's groups behind them
     const uint64_t nd = std::min(dense_n, n);
     if (nd) {
-      HIP_TRY(hipMemcpyAsync(d_rec, q->d_dense, nd * (nwords + 1) * 8, hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(d_rec, view.dense, nd * (nwords + 1) * 8, hipMemcpyDeviceToDevice, s));
     }
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
     if (n > nd) {
@@ -2433,7 +2518,7 @@ Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n,
   }
   OrderKeyArgs ok{};
   if (n > 0) {
-    const KernelPlan& kp = q->kp;
+    const KernelPlan& kp = q->rplan();
     const ExprPtr& e0 = order[0].call;
     if (e0->kind != Expr::INPUT) {
       return Status::error(EVQL_ENOTSUP, "first sort expression is not a plain output column");
@@ -2555,7 +2640,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
     st = order_fetched(q);
     if (!st.ok()) return st;
   }
-  const KernelPlan& kp = q->kp;
+  const KernelPlan& kp = q->rplan();
   const size_t nsel = q->select.size();
   const bool partial = q->group_mode == EVQL_MODE_PARTIAL;
   q->out_cols.assign(partial ? 2 : nsel, std::vector<uint8_t>());
@@ -2673,7 +2758,7 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
 // the select-list values of fetched record g (EVQL_MODE_FINAL), as the emission
 // loop above computes them; ORDER BY evaluates its sort expressions over these
 static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* outs) {
-  const KernelPlan& kp = q->kp;
+  const KernelPlan& kp = q->rplan();
   const size_t nsel = q->select.size();
   const size_t rw = q->rec_stride;
   const uint32_t nc = uint32_t(kp.cols.size());

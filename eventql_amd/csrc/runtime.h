@@ -154,6 +154,29 @@ struct MaterializedColumn {
   }
 };
 
+// Dictionary of a STRING column: one dense 32-bit code per distinct value, EXACT (equal
+// codes <=> equal bytes, verified when it is built, string_dict.cc).  A GROUP BY over the
+// column then runs on the codes -- a 4-byte exact key instead of 64-bit hashes plus a row
+// index -- and its group records are translated back (code -> hashed identity + first
+// row) only where they leave the operator.
+struct StringDict {
+  bool tried = false;
+  bool usable = false;
+  uint64_t n_codes = 0;
+  uint32_t* d_codes = nullptr;       // per row, padded like the other column buffers
+  uint64_t* d_code_pages = nullptr;  // "page" offsets into d_codes (131,072 codes each)
+  uint64_t* d_entries = nullptr;     // [n_codes][3]: string hash, first row, bit0 NULL
+  std::string why;                   // when not usable
+  StringDict() = default;
+  StringDict(const StringDict&) = delete;
+  StringDict& operator=(const StringDict&) = delete;
+  ~StringDict() {
+    if (d_codes) hipFree(d_codes);
+    if (d_code_pages) hipFree(d_code_pages);
+    if (d_entries) hipFree(d_entries);
+  }
+};
+
 struct evql_table {
   evql_ctx* ctx = nullptr;
   evql::TableLayout layout;
@@ -163,6 +186,7 @@ struct evql_table {
   std::vector<std::vector<uint64_t*>> d_pages;
   std::vector<uint64_t> payload_bytes;
   std::map<std::string, MaterializedColumn> materialized;
+  std::map<std::string, StringDict> dicts;  // by column name
   // maximum |value| per column ("name#f" float view, "name#u" integer view): bounds of
   // exact float sums (EVQL_FLOAT_SUM_EXACT)
   std::map<std::string, double> col_absmax;
@@ -200,6 +224,17 @@ struct evql_query {
   evql::LoweredProgram where;
   bool has_where = false;
   evql::KernelPlan kp;
+  // Dictionary-coded string key (StringDict): `kp` is then the plan the kernels run --
+  // KEY_EXACT over the code column -- and `rkp` the plan its group RECORDS follow once
+  // they leave the scan (hashed string key + first row: what the plan is without a
+  // dictionary).  Emission, ORDER BY, the exchange and chain merges read rplan().
+  bool dict_key = false;
+  int dict_candidate = -1;  // scan column a dictionary could code (planner), or -1
+  evql::KernelPlan rkp;
+  const evql::KernelPlan& rplan() const { return dict_key ? rkp : kp; }
+  uint64_t* d_conv = nullptr;  // the groups as records of rplan()'s layout
+  uint64_t conv_cap = 0;       // records
+  bool conv_valid = false;
   std::vector<int> select_agg_index;  // select expr -> index into kp.aggs or -1
   std::vector<bool> select_passthrough;
   uint32_t group_mode = EVQL_MODE_FINAL;
@@ -333,6 +368,15 @@ Status table_rt_column(evql_table* t, const std::string& name, RtColumn* out,
                        const uint64_t** strpos);
 // device copies of the page offset lists of `t->layout` -> t->d_pages
 Status upload_page_tables(evql_table* t);
+// string_dict.cc: the (cached) dictionary of STRING column `li`; built on first use
+Status table_string_dict(evql_table* t, int li, StringDict** out);
+// the query's groups as dense records of rplan()'s layout: `dense` holds the first `nd`
+// groups, the remaining ngroups - nd sit in the HBM group table (compact them from there)
+struct RecordsView {
+  const uint64_t* dense = nullptr;
+  uint64_t nd = 0;
+};
+Status query_records_view(evql_query* q, RecordsView* out);
 // device_writer.cc: a cstable v0.2.0 image encoded on the device from SoA columns
 struct DeviceColumnIn {
   const uint64_t* values;  // device, num_rows value words
