@@ -84,6 +84,10 @@ struct KernelPlan {
   // of tuples, then aggregate each bucket in LDS (codegen_kernels.inc)
   bool partitioned = false;
   int part_bits = 12;
+  // two-level partitioning without the count pass: tuples go into slack-allocated coarse
+  // buckets (capacity EvqlPartArgs::coarse_cap each), the fine-bucket sizes are counted
+  // while they are scattered; false = exact offsets from evql_part_count first
+  bool part_fused = false;
   // partition tuples are arrays of 32-bit words: the identity of a single unsigned key
   // and the first-row index travel as 32 bits where the table's statistics bound them
   bool narrow_ident = false;

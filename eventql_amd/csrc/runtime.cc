@@ -133,7 +133,10 @@ Status compile_kernel(evql_ctx* ctx, const std::string& source, Module* out, boo
     }
     HIP_TRY(hipModuleGetFunction(&out->fn, out->mod, "evql_scan_agg"));
     if (source.find("evql_part_aggregate") != std::string::npos) {
-      HIP_TRY(hipModuleGetFunction(&out->fn_count, out->mod, "evql_part_count"));
+      out->fn_count = nullptr;  // (absent from the fused form, KernelPlan::part_fused)
+      if (source.find("evql_part_count(") != std::string::npos) {
+        HIP_TRY(hipModuleGetFunction(&out->fn_count, out->mod, "evql_part_count"));
+      }
       HIP_TRY(hipModuleGetFunction(&out->fn_scatter, out->mod, "evql_part_scatter"));
       HIP_TRY(hipModuleGetFunction(&out->fn_aggregate, out->mod, "evql_part_aggregate"));
       if (source.find("evql_part_refine") != std::string::npos) {
@@ -1433,6 +1436,17 @@ static Status compile_plan_kernels(evql_query* q) {
   if (q->kp.partitioned) {
     Status stw = choose_tuple_widths(q);
     if (!stw.ok()) return stw;
+    // two partition levels: without the count pass, unless a coarse bucket overflowed its
+    // slack before (skewed keys) or the tuple buffers have to be sized by an exact count
+    // (very large scans with a selective predicate, query_launch)
+    evql_table* t = q->table;
+    const uint64_t nrows = q->nested ? q->nested_rows : t->layout.num_rows;
+    const uint64_t begin = std::min(q->row_begin, nrows);
+    const uint64_t end = q->row_end ? std::min(q->row_end, nrows) : nrows;
+    q->kp.part_fused = false;
+    const uint64_t tw = uint64_t(partition_tuple_u32_words(q->kp)) / 2;
+    q->kp.part_fused = q->kp.part_bits > 8 && !q->part_fused_off &&
+                       (end - begin) * tw * 8 <= (16ull << 30);
   }
   q->source = generate_kernel_source(q->kp);
   Status st = compile_kernel(ctx, q->source, &q->module, true);
@@ -1781,34 +1795,54 @@ Status query_launch(evql_query* q) {
     size_t psz = sizeof(HostArgsWithPart);
     void* pconfig[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ap, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz,
                        HIP_LAUNCH_PARAM_END};
-    HIP_TRY(hipEventRecord(q->ev0, s));
-    HIP_TRY(hipModuleLaunchKernel(q->module.fn_count, unsigned(nwg), 1, 1, kp.block, 1, 1, 0, s,
-                                  nullptr, pconfig));
-    HIP_TRY(hipMemsetAsync(q->d_bucket_start, 0, (npart + 2) * 8, s));
-    HIP_TRY(launch_part_scan(q->d_part_counts, npart, nwg, q->d_bucket_start, s));
-    uint64_t* d_total = q->d_bucket_start + npart + 1;
-    HIP_TRY(launch_exclusive_scan(q->d_bucket_start, npart + 1, d_total, s));
     const uint64_t tw = uint64_t(partition_tuple_u32_words(kp)) / 2;  // 8-byte words
     const uint64_t span = a.row_end - a.row_begin;
+    uint64_t* d_total = q->d_bucket_start + npart + 1;
+    const bool fused = kp.part_fused && two_level;
+    HIP_TRY(hipEventRecord(q->ev0, s));
+    HIP_TRY(hipMemsetAsync(q->d_bucket_start, 0, (npart + 2) * 8, s));
     uint64_t ntuples = span;  // upper bound: every row passes
-    if (q->tuples_cap < span && span * tw * 8 > (16ull << 30)) {
-      // large scans with a selective predicate: size the buffers by the count pass
-      HIP_TRY(hipMemcpyAsync(&ntuples, d_total, 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+    if (!fused) {
+      HIP_TRY(hipModuleLaunchKernel(q->module.fn_count, unsigned(nwg), 1, 1, kp.block, 1, 1, 0, s,
+                                    nullptr, pconfig));
+      HIP_TRY(launch_part_scan(q->d_part_counts, npart, nwg, q->d_bucket_start, s));
+      HIP_TRY(launch_exclusive_scan(q->d_bucket_start, npart + 1, d_total, s));
+      if (q->tuples_cap < span && span * tw * 8 > (16ull << 30)) {
+        // large scans with a selective predicate: size the buffers by the count pass
+        HIP_TRY(hipMemcpyAsync(&ntuples, d_total, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+      }
     }
     if (ntuples > q->tuples_cap) {
       if (q->d_tuples) hipFree(q->d_tuples);
-      if (q->d_tuples_tmp) hipFree(q->d_tuples_tmp);
-      q->d_tuples = q->d_tuples_tmp = nullptr;
+      q->d_tuples = nullptr;
       const uint64_t cap = ntuples + ntuples / 16 + 1024;
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_tuples), cap * tw * 8));
-      if (two_level) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_tuples_tmp), cap * tw * 8));
       q->tuples_cap = cap;
+    }
+    if (two_level) {
+      // coarse-bucket order.  Fused form: every coarse bucket owns a fixed range with 5 %
+      // slack over an even share of the rows (+ one tile's worth); the hash spreads the
+      // tuples evenly (64 buckets of ~2e6 tuples deviate by ~0.1 %), a bucket that
+      // overflows anyway (one dominant key) voids the launch: exact offsets then
+      const uint64_t ncoarse = 64;
+      ap.p.coarse_cap = span / ncoarse + span / (ncoarse * 20) + 16384;
+      const uint64_t want = fused ? ap.p.coarse_cap * ncoarse : q->tuples_cap;
+      if (want > q->tuples_tmp_cap) {
+        if (q->d_tuples_tmp) hipFree(q->d_tuples_tmp);
+        q->d_tuples_tmp = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_tuples_tmp), want * tw * 8));
+        q->tuples_tmp_cap = want;
+      }
     }
     ap.p.tuples = q->d_tuples;
     ap.p.tuples_tmp = q->d_tuples_tmp;
     HIP_TRY(hipModuleLaunchKernel(q->module.fn_scatter, unsigned(nwg), 1, 1, kp.block, 1, 1, 0, s,
                                   nullptr, pconfig));
+    if (fused) {
+      // the fine-bucket sizes the scatter counted -> bucket_start[]
+      HIP_TRY(launch_exclusive_scan(q->d_bucket_start, npart + 1, d_total, s));
+    }
     // two workgroups per CU where the resources allow it: both passes wait on
     // dependent loads (tuple -> slot) and hide each other's latency
     const uint64_t wide = std::max<uint64_t>(uint64_t(q->grid), uint64_t(ctx->num_cus) * 2);
@@ -1901,6 +1935,16 @@ Status query_finish(evql_query* q) {
     if (status[0] & 4u) return Status::error(EVQL_ERUNTIME, "modulo by zero");
     if (status[0] & 32u) {
       return Status::error(EVQL_ERUNTIME, "exact float sum: a value is not finite or exceeds the bound");
+    }
+    if (status[0] & 64u) {
+      // a coarse bucket outgrew its slack (skewed keys): exact offsets from the count pass
+      q->part_fused_off = true;
+      Status stc = compile_plan_kernels(q);
+      if (!stc.ok()) return stc;
+      beat(q);
+      Status st = query_launch(q);
+      if (!st.ok()) return st;
+      continue;
     }
     if (status[0] & (2u | 8u | 16u)) {
       // group table / count_distinct pair set / dense record buffer too small: grow

@@ -73,6 +73,7 @@ struct HostPartArgs {
   uint32_t* cursors;
   uint64_t* dense;
   uint64_t dense_cap;
+  uint64_t coarse_cap;  // tuples per coarse bucket of tuples_tmp (KernelPlan::part_fused)
 };
 struct HostArgsWithPart {
   HostArgs a;
@@ -260,6 +261,8 @@ struct evql_query {
   uint64_t* d_tuples_tmp = nullptr;  // coarse-bucket order (two-level scatter)
   uint32_t* d_part_cursors = nullptr;
   uint64_t tuples_cap = 0;  // in tuples
+  uint64_t tuples_tmp_cap = 0;  // in tuples
+  bool part_fused_off = false;  // a coarse bucket overflowed its slack once: exact offsets from now on
   // partitioned path: the groups of every bucket that fitted its LDS table, as dense
   // records [kind, identity, (identity 2), (first row), states...]; the HBM table
   // then only holds the groups of overflowed buckets

@@ -1203,6 +1203,48 @@ def test_plan_without_a_hint_finds_the_partitioned_path_by_itself(ctx):
         t.close()
 
 
+def test_partitioned_path_with_a_dominant_key(ctx):
+    """the fused two-level partitioning gives every coarse bucket a slack-allocated range
+    (no count pass); half of the rows carrying ONE key overflow that key's range: the
+    launch is void, the operator falls back to exact offsets (evql_part_count) and the
+    result is the same"""
+    n = 6_000_000
+    rng = np.random.default_rng(77)
+    u = rng.integers(0, 2_000_000, n).astype(np.uint64)
+    u[rng.random(n) < 0.5] = 1234567
+    a = rng.integers(0, 65536, n).astype(np.uint64)
+    w = E.Writer([dict(name="u", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+                  dict(name="a", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN)])
+    w.put("u", u)
+    w.put("a", a)
+    w.commit(n)
+    img = w.image()
+    w.close()
+    t = ctx.open_image(img)
+    try:
+        S = dict(u=K.T_UINT64, a=K.T_UINT64)
+        plan = Plan(S, select=[col("u"), count(1), sum_(col("a")), max_(col("a"))],
+                    group_by=[col("u")], groups_hint=2_000_000)
+        q = t.query(plan)
+        assert "evql_part_refine" in q.kernel_source() and "evql_part_count(" not in q.kernel_source()
+        got = q.run()
+        assert "evql_part_count(" in q.kernel_source()       # fell back
+        keys, cnt = np.unique(u, return_counts=True)
+        assert got.nrows == len(keys)
+        rows = {r[0]: r for r in got.rows()}
+        assert rows[1234567][1] == int(cnt[keys == 1234567][0])
+        assert rows[1234567][2] == int(a[u == 1234567].sum())
+        sample = keys[:: max(1, len(keys) // 500)]
+        for kk in sample:
+            m = u == kk
+            assert rows[int(kk)][1:] == (int(m.sum()), int(a[m].sum()), int(a[m].max()))
+        # the same operator again: exact offsets right away
+        assert q.run().nrows == len(keys)
+        q.close()
+    finally:
+        t.close()
+
+
 def test_hint_less_plan_over_keys_that_follow_the_row_order(ctx):
     """a time-ordered table: the key grows with the row number, so a prefix of the scan
     holds a handful of groups while the table has 90,000.  The probe samples row ranges

@@ -139,3 +139,60 @@ def test_truncated_string_stream_is_an_error(ctx):
         assert ei.value.code == K.EVQL_EIO and "end of column" in ei.value.msg
     finally:
         t.close()
+
+
+def test_string_keys_run_on_the_tables_dictionary(ctx):
+    """one STRING key that is only grouped by and selected: the kernels group by the
+    column's dictionary codes (string_dict.cc) -- exact 32-bit identities, no hashing in
+    the row function -- and everything downstream (emission, ORDER BY, PARTIAL rows, the
+    first-row strings) still sees the plan's string key.  Plans that read the column
+    elsewhere, or other first-row values, keep the hashed identity."""
+    from eventql_amd.plan import Order
+    rng = np.random.default_rng(5)
+    n = 120_000
+    u = rng.integers(0, 40_000, n)
+    vals = [b"" if k % 97 == 0 else (b"key/%d" % k if k % 3 else b"k%dx" % k) * (1 + k % 4) for k in u]
+    present = (rng.random(n) >= 0.05).astype(np.uint8)
+    for img in (build(vals), build(vals, present=present)):
+        t = ctx.open_image(img)
+        s, x = col("s"), col("x")
+        coded = [Plan(S, select=[s, count(1), sum_(x)], group_by=[s]),
+                 Plan(S, select=[count(1), s, sum_(x % 7)], group_by=[s], where=Call("eq", x % 3, lit(1))),
+                 Plan(S, select=[s, count(1)], group_by=[s], groups_hint=100_000)]
+        hashed = [Plan(S, select=[s, x, count(1)], group_by=[s]),                 # first row of x
+                  Plan(S, select=[s, count(1)], group_by=[s], where=s >= "key/2"),  # bytes in WHERE
+                  Plan(S, select=[s, x % 2, count(1)], group_by=[s, x % 2])]       # two keys
+        for plan, want_dict in [(p, True) for p in coded] + [(p, False) for p in hashed]:
+            exp = O.oracle_run(img, plan)
+            q = t.query(plan)
+            src = q.kernel_source()
+            assert ("evql_ident_add" not in src) == want_dict, plan.select
+            got = q.run()
+            assert got.nrows == exp.nrows
+            # (first-row values of non-key columns are compared too: one table, one scan order)
+            ki = [i for i, p in enumerate(plan.select) if p.return_type == K.T_STRING][0]
+            if len(plan.group) == 2:
+                key = lambda r: (r[0], r[1])
+            else:
+                key = lambda r: r[ki]
+            assert sorted(got.rows(), key=lambda r: repr(key(r))) == \
+                sorted(exp.rows(), key=lambda r: repr(key(r)))
+            q.close()
+        # PARTIAL rows of a coded plan: SHA1 keys + states, byte for byte
+        pp = Plan(S, select=[s, count(1), sum_(x)], group_by=[s], mode=K.MODE_PARTIAL)
+        q = t.query(pp)
+        assert "evql_ident_add" not in q.kernel_source()
+        got = sorted(q.run().rows())
+        q.close()
+        ep = O.oracle_run(img, pp)
+        want = sorted((ep.keys[20 * i:20 * i + 20], ep.columns[0][i]) for i in range(ep.nrows))
+        assert got == want
+        # ORDER BY count desc, then the string key, LIMIT: over the translated records
+        p2 = Plan(S, select=[s, count(1)], group_by=[s])
+        order = Order(p2, [(1, True), (0, False)], limit=9, offset=1)
+        q = t.query(p2)
+        q.set_order(order)
+        got = q.run().rows()
+        q.close()
+        assert got == O.oracle_run(img, p2, order=order).rows()
+        t.close()
