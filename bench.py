@@ -276,7 +276,9 @@ def main():
             qq.finish()
             n = drain(qq)
             step.stats = qq.stats()
-            step.kernel_ms = step.stats["kernel_ms"]
+            # both kernels of the operator: k_within_record (per-record reduction) and
+            # evql_scan_agg (the GROUP BY over the per-record values)
+            step.kernel_ms = step.stats["total_ms"]
             qq.close()
             return n
         q.launch()
@@ -316,6 +318,17 @@ def main():
             ngroups_out = int(g.item())
 
     stats = getattr(step, "stats", None) or q.stats()
+    drain_info = None
+    if high_card and world == 1:
+        # OUTSIDE ms_per_step: every group of the last step pulled through nextBatch
+        # (GroupByExpression::nextBatch -> packed SVector bytes, 1024 rows per call as the
+        # reference's ResultCursor asks)
+        torch.cuda.synchronize()
+        t0d = time.perf_counter()
+        nd = drain(q)
+        ddt = time.perf_counter() - t0d
+        drain_info = dict(groups=int(nd), drain_ms=ddt * 1e3, groups_per_s=nd / ddt,
+                          batch_rows=1024)
     if rank == 0:
         total_rows = rows * world * args.steps
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
@@ -332,6 +345,16 @@ def main():
                         "hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the kernels `kernel_ms` covers (hipEvents around them on the context's stream)
+        if args.workload == "config5w":
+            kernel_names = "k_within_record + evql_scan_agg"
+        elif "evql_part_scatter" in q.kernel_source():
+            src = q.kernel_source()
+            kernel_names = " + ".join(k for k in ("evql_part_count", "evql_part_scatter",
+                                                  "evql_part_refine", "evql_part_aggregate")
+                                      if (k + "(") in src)
+        else:
+            kernel_names = "evql_scan_agg"
         merge = "none"
         if world > 1:
             merge = ("%s: group records bucketed by owner on the device, all-to-all, merged in "
@@ -372,7 +395,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "evql_scan_agg",
+                "kernel": kernel_names,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -414,12 +437,21 @@ def main():
                 sample = args.cpu_sample_rows or (4_000_000 if high_card else 80_000_000)
                 out["cpu_baseline"] = cpu_baseline(ctx, plan_fn, columns, sample,
                                                    workload=args.workload, **gen_kw)
+        if drain_info:
+            out["config"]["drain_after_last_step"] = drain_info
         if world > 1:
+            # phases of the exchange step of the last timed step on rank 0 (evql_exchange_
+            # last_stats: export = records + first rows + owner buckets, transfer = the
+            # all_gather of counts + all-to-all, merge = merge kernels + recount), beside
+            # the scan kernels' device time
+            out_x["scan_kernel_ms"] = avg_kernel_ms
             out["config"]["exchange_last_step"] = out_x
         if leb or string_keys:
             out["config"]["materialize_ms_first_operator"] = materialize_ms
         if string_keys:
-            out["config"]["encodings"] = "s STRING_PLAIN (boundaries + 64-bit hashes found on the device once per table), a UINT64_PLAIN, v FLOAT_IEEE754"
+            out["config"]["encodings"] = ("s STRING_PLAIN (value boundaries, 64-bit hashes and the exact "
+                                          "dictionary of dense 32-bit codes built on the device once per "
+                                          "table), a UINT64_PLAIN, v FLOAT_IEEE754")
         if nested:
             # the Dremel flattening (level decode, slot maps, LEB128 decode) runs when
             # the first operator over these columns is created (together with the

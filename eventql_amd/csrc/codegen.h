@@ -80,6 +80,9 @@ struct KernelPlan {
   int block = 256;
   int unroll = 4;
   int lds_slots = 0;  // 0 => aggregate straight into the HBM table
+  // entries of the lane-private accumulator cache in front of the LDS table (1, or 4 for
+  // plans with 2 .. 4 expected groups), codegen_kernels.inc evql_update
+  int lane_cache = 1;
   // high cardinality: radix-partition the passing rows into 2^part_bits buckets
   // of tuples, then aggregate each bucket in LDS (codegen_kernels.inc)
   bool partitioned = false;

@@ -142,6 +142,7 @@ void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
   KernelPlan& kp = *kpp;
   kp.block = 256;
   kp.partitioned = false;
+  kp.lane_cache = 1;
   // loads in flight per lane = columns x unroll; ~16 saturate HBM (measured: 2
   // columns 2.54 ms at unroll 4, 2.43 ms at unroll 8; 4 columns spill at 8)
   kp.unroll = kp.cols.size() <= 2 ? 8 : 4;
@@ -200,6 +201,11 @@ void choose_launch_shape(KernelPlan* kpp, uint64_t hint) {
     }
     kp.lds_slots = int(s);
     kp.block = 1024;
+    // 2 .. 4 groups: half, a third, a quarter of a wave's rows meet on ONE LDS address and
+    // the atomics serialise (config 2's query, 2e8 rows: 1.03 / 0.82 / 0.71 ms for 2 / 3 / 4
+    // groups against 0.50 ms for 9 and 0.56 ms for 1000).  Four lane-private accumulators
+    // then hold every group a lane meets (codegen_kernels.inc evql_update).
+    kp.lane_cache = (hint >= 2 && hint <= 4) ? 4 : 1;
     // (measured, round 2: a 2048-slot table runs dense keys as fast as 4096 slots, but the
     //  freed LDS does not buy a second workgroup per CU: at 64 VGPRs per wave the kernel
     //  spills -- config 3 over 16-bit pages 0.38 -> 1.03 ms; with unroll 2 on top 0.50 ms,

@@ -1075,8 +1075,18 @@ static Status materialize_within_record(evql_query* q) {
     q->nested_flat[e] = d_out;
     q->nested_owned.push_back(d_out.release());
   }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
   HIP_TRY(launch_within_record(a, s));
+  HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipStreamSynchronize(s));
+  float wms = 0;
+  hipEventElapsedTime(&wms, e0, e1);
+  q->within_record_ms = wms;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
   q->nested_rows = nrec;
   return Status();
 }
@@ -1551,6 +1561,12 @@ static Status probe_cardinality(evql_query* q) {
     choose_launch_shape(&q->kp, hint);
     return compile_plan_kernels(q);
   }
+  if (d >= 2 && d <= 4 && p >= 4096) {
+    // a handful of groups among thousands of sampled rows: the shape for 2 .. 4 groups
+    // (four lane-private accumulators, choose_launch_shape)
+    choose_launch_shape(&q->kp, uint64_t(d));
+    if (q->kp.lane_cache > 1) return compile_plan_kernels(q);
+  }
   return Status();
 }
 
@@ -1990,7 +2006,8 @@ Status query_finish(evql_query* q) {
     float ms = 0;
     hipEventElapsedTime(&ms, q->ev0, q->ev1);
     q->stats.kernel_ms = ms;
-    q->stats.total_ms = ms;
+    // (a record scan's per-record reduction ran when the operator was built)
+    q->stats.total_ms = ms + q->within_record_ms;
     uint64_t counters[8];
     HIP_TRY(hipMemcpy(counters, q->d_counters, 64, hipMemcpyDeviceToHost));
     q->stats.rows_passed = counters[0];

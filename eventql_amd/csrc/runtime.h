@@ -303,6 +303,7 @@ struct evql_query {
     uint32_t level = 0;  // select_list_[i].rep_level
   };
   bool within_record = false;
+  double within_record_ms = 0;  // device time of k_within_record (part of this operator's work)
   std::vector<evql::ColAccess> wr_cols;  // the columns the record scan reads
   std::vector<WithinAgg> wr_aggs;
   std::string source;

@@ -24,8 +24,8 @@ def mixed(ctx):
     t.close()
 
 
-def check(t, img, key_cols=1, **kw):
-    plan = Plan(T.MIXED_SCHEMA, **kw)
+def check(t, img, key_cols=1, schema=None, **kw):
+    plan = Plan(schema or T.MIXED_SCHEMA, **kw)
     exp = O.oracle_run(img, plan)
     q = t.query(plan)
     try:
@@ -60,14 +60,44 @@ def test_config_shapes(mixed):
           group_by=[col("k")], where=W, groups_hint=1000)
 
 
-@pytest.mark.parametrize("hint", [0, 10, 1000, 5000, 100000])
+@pytest.mark.parametrize("hint", [0, 2, 4, 10, 1000, 5000, 100000])
 def test_group_table_variants(mixed, hint):
-    """LDS table sizes, the one-workgroup-per-CU variant and the HBM-only table"""
+    """LDS table sizes, the one-workgroup-per-CU variant and the HBM-only table; hints of
+    2 .. 4 select the four-entry lane-private accumulator cache (here with 1000 groups:
+    every row evicts)"""
     t, img, _ = mixed
     _, _, st = check(t, img, select=[col("k"), sum_(col("a")), count(1), min_(col("b")),
                                      max_(col("v"))],
                      group_by=[col("k")], where=col("a") > 1000, groups_hint=hint)
     assert st["num_groups"] == 1000
+
+
+@pytest.mark.parametrize("ngroups", [1, 2, 3, 4])
+def test_very_few_groups(ctx, ngroups):
+    """1 .. 4 groups, first-row values, min / max / float sums, nullable keys: the rows of
+    a lane are combined in its accumulator cache and reach the LDS table only at the end"""
+    n = 700_001
+    i = np.arange(n, dtype=np.uint64)
+    w = E.Writer([dict(name="g", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN,
+                       dlevel_max=1),
+                  dict(name="a", logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN),
+                  dict(name="v", logical_type=K.COL_FLOAT, storage_type=K.ENC_FLOAT_IEEE754)])
+    g = (i * np.uint64(2654435761) >> np.uint64(7)) % np.uint64(ngroups)
+    w.put("g", g, present=(i % 11 != 3).astype(np.uint8))
+    w.put("a", (i * np.uint64(40503)) % np.uint64(65521))
+    w.put("v", ((i * np.uint64(7919)) % np.uint64(4096)).astype(np.float64) / 8.0)
+    w.commit(n)
+    img = w.image()
+    w.close()
+    t = ctx.open_image(img)
+    S = dict(g=K.T_UINT64, a=K.T_UINT64, v=K.T_FLOAT64)
+    try:
+        for hint in (0, ngroups + 1):
+            check(t, img, select=[col("g"), col("a"), count(1), sum_(col("a")), min_(col("v")),
+                                  max_(col("a")), sum_(col("v"))],
+                  group_by=[col("g")], where=col("a") > 100, groups_hint=hint, schema=S)
+    finally:
+        t.close()
 
 
 def test_high_cardinality(mixed):
