@@ -1128,6 +1128,90 @@ __global__ void __launch_bounds__(kBlock) k_lsm_filter(LsmArgs a) {
   }
 }
 
+// ---- result emission on the device ---------------------------------------------------
+constexpr u8 kStagNull = 1;  // STAG_NULL, sql/svalue.h:52-56
+__device__ __forceinline__ void emit_store9(u8* out, u64 i, u64 bits, u8 tag) {
+  u8* p = out + i * 9;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) p[b] = (u8) (bits >> (8 * b));
+  p[8] = tag;
+}
+
+__global__ void __launch_bounds__(kBlock) k_extract_word(const u64* records, u64 n, u32 rw, u32 word,
+                                                         u64* out) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    out[i] = records[i * rw + word];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_emit_fixed(const EmitArgs* ap, u64 n) {
+  const EmitArgs& a = *ap;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64* rec = (const u64*) a.records + i * a.rw;
+    for (u32 c = 0; c < a.ncols; ++c) {
+      const EmitCol& e = a.col[c];
+      if (e.elem == 0) continue;  // strings: k_emit_str_*
+      u64 bits = 0;
+      u8 tag = 0;
+      if (e.kind == 0) {
+        if (rec[0] == 2) tag = kStagNull; else bits = rec[1];
+      } else if (e.kind == 1) {
+        bits = rec[e.word];
+        if (e.count_word >= 0) {
+          const u64 cnt = rec[e.count_word];
+          if (cnt == 0) {
+            bits = 0;
+            tag = kStagNull;
+          } else if (e.is_mean) {
+            const double m = evql_as_f64(bits) / (double) cnt;
+            bits = evql_f64_bits(m);
+          }
+        }
+      } else {
+        const u64 raw = ((const u64*) a.first_vals)[(u64) e.src * n + i];
+        tag = a.first_tags[(u64) e.src * n + i] & 1 ? kStagNull : 0;
+        bits = e.to_float ? evql_f64_bits((double) raw) : raw;
+      }
+      if (e.elem == 2) {  // BOOL: value byte, tag byte
+        e.out[i * 2] = (u8) (bits != 0);
+        e.out[i * 2 + 1] = tag;
+      } else {
+        emit_store9(e.out, i, bits, tag);
+      }
+    }
+  }
+}
+
+// STRING elements: u32 length, bytes, tag (a NULL string is length 0 with STAG_NULL)
+__global__ void __launch_bounds__(kBlock) k_emit_str_sizes(const EmitArgs* ap, u32 c, u64 n, u64* sizes) {
+  const EmitArgs& a = *ap;
+  const EmitCol& e = a.col[c];
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const bool null = a.first_tags[(u64) e.src * n + i] & 1;
+    const u64 sp = ((const u64*) a.first_vals)[(u64) e.src * n + i];
+    sizes[i] = 5 + (null ? 0 : (sp >> 40));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_emit_str_bytes(const EmitArgs* ap, u32 c, u64 n) {
+  const EmitArgs& a = *ap;
+  const EmitCol& e = a.col[c];
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const bool null = a.first_tags[(u64) e.src * n + i] & 1;
+    const u64 sp = ((const u64*) a.first_vals)[(u64) e.src * n + i];
+    const u32 len = null ? 0u : (u32) (sp >> 40);
+    const u64 off = sp & kStrOffMask;
+    u8* p = e.out + ((const u64*) e.offsets)[i];
+    p[0] = (u8) len; p[1] = (u8) (len >> 8); p[2] = (u8) (len >> 16); p[3] = (u8) (len >> 24);
+    for (u32 k = 0; k < len; ++k) p[4 + k] = vbyte_fwd(a.image, (const u64*) e.pages, off + k);
+    p[4 + len] = null ? kStagNull : 0;
+  }
+}
+
 // ---- string dictionaries (string_dict.cc) ---------------------------------------------
 // records of the dictionary's GROUP BY over the column's 64-bit string hash:
 // [kind, hash, first row, count]; record i becomes code i
@@ -1930,6 +2014,34 @@ hipError_t launch_dict_records(const uint64_t* in, uint64_t n, uint32_t in_words
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_dict_records, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) in, (u64) n,
                      in_words, (const u64*) entries, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_extract_word(const uint64_t* records, uint64_t n, uint32_t rw, uint32_t word,
+                               uint64_t* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_extract_word, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) records, (u64) n,
+                     rw, word, (u64*) out);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit_fixed(const EmitArgs* d_args, uint64_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_emit_fixed, dim3(grid_for(n)), dim3(kBlock), 0, s, d_args, (u64) n);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit_str_sizes(const EmitArgs* d_args, uint32_t c, uint64_t n, uint64_t* sizes,
+                                 hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_emit_str_sizes, dim3(grid_for(n)), dim3(kBlock), 0, s, d_args, c, (u64) n,
+                     (u64*) sizes);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit_str_bytes(const EmitArgs* d_args, uint32_t c, uint64_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_emit_str_bytes, dim3(grid_for(n)), dim3(kBlock), 0, s, d_args, c, (u64) n);
   return hipGetLastError();
 }
 

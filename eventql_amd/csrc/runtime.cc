@@ -292,6 +292,12 @@ evql_query::~evql_query() {
   if (d_dense) hipFree(d_dense);
   if (d_mtab) hipFree(d_mtab);
   if (d_conv) hipFree(d_conv);
+  for (auto* p : demit.col) {
+    if (p) hipHostFree(p);
+  }
+  for (auto* p : demit.off) {
+    if (p) hipHostFree(p);
+  }
   for (auto* p : nested_owned) hipFree(p);
   if (ev0) hipEventDestroy(ev0);
   if (ev1) hipEventDestroy(ev1);
@@ -2155,6 +2161,194 @@ Status query_reset(evql_query* q) {
   return Status();
 }
 
+// ---------------------------------------------------------------------------
+// large results: the output columns packed on the device
+// ---------------------------------------------------------------------------
+// GroupByExpression::nextBatch (groupby.cc:187-220) runs `method_call` of every select
+// expression per group and appends the value to the column's SVector.  For 1e7 groups the
+// host loop (record copy, sort, one eval_expr per cell) took seconds.  When every select
+// expression is the group key, a bare aggregate or the first-row value of a scan column --
+// config 4 / 4s, and what `select k, count(1), sum(x) .. group by k` looks like -- one
+// kernel writes the packed SVector bytes (svalue.cc:410-517) of every column for ALL groups;
+// the host copies each column once into pinned memory and next_batch hands out slices.
+// Row order is unspecified for a GROUP BY; small results keep the host path
+// and its deterministic order.
+static const uint64_t kDeviceEmitMinGroups = 1 << 16;
+
+static bool device_emit_columns(const evql_query* q, bool merged, EmitArgs* ea) {
+  const KernelPlan& kp = q->rplan();
+  const size_t nsel = q->select.size();
+  if (q->group_mode != EVQL_MODE_FINAL || !q->order.empty() || q->has_limit) return false;
+  if (nsel == 0 || nsel > kMaxEmitCols) return false;
+  for (size_t i = 0; i < nsel; ++i) {
+    const LoweredProgram& lp = q->select[i];
+    EmitCol& e = ea->col[i];
+    e = EmitCol{};
+    e.count_word = -1;
+    e.stype = lp.return_type;
+    e.elem = lp.return_type == EVQL_T_BOOL ? 2 : 9;
+    if (lp.return_type == EVQL_T_NIL) return false;
+    if (lp.is_aggregate) {
+      if (lp.call->kind != Expr::AGG_GET) return false;  // post-aggregate arithmetic: host
+      const AggPlan& a = kp.aggs[q->select_agg_index[i]];
+      if (a.exact_index >= 0) return false;  // (128-bit rounding of an exact sum: host)
+      e.kind = 1;
+      e.word = uint32_t(1 + kp.state_word_base() + a.first_word);
+      switch (a.fn) {
+        case EVQL_AGG_COUNT: case EVQL_AGG_SUM_UINT64: case EVQL_AGG_SUM_INT64:
+        case EVQL_AGG_SUM_FLOAT64: case EVQL_AGG_COUNT_DISTINCT_UINT64:
+          break;
+        case EVQL_AGG_MEAN_UINT64: case EVQL_AGG_MEAN_INT64: case EVQL_AGG_MEAN_FLOAT64:
+          e.is_mean = 1;
+          e.count_word = int32_t(e.word + 1);
+          break;
+        default:  // min / max
+          e.count_word = int32_t(e.word + 1);
+      }
+    } else if (q->select_passthrough[i]) {
+      if (lp.return_type == EVQL_T_STRING) return false;
+      e.kind = 0;
+    } else {
+      // a bare column: select expr = X_INPUT(j) of the scan select list = X_INPUT(c)
+      if (merged || !kp.need_first_row || lp.call->kind != Expr::INPUT) return false;
+      const uint32_t j = lp.call->input;
+      if (j >= q->scan_select.size() || q->scan_select[j].call->kind != Expr::INPUT) return false;
+      const uint32_t c = q->scan_select[j].call->input;
+      if (c >= kp.cols.size() || q->nested) return false;
+      const ColAccess& ca = kp.cols[c];
+      if (ca.stype != lp.return_type) return false;
+      e.kind = 2;
+      e.src = c;
+      e.to_float = ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float;
+      if (ca.string_hash) e.elem = 0;
+    }
+  }
+  ea->ncols = uint32_t(nsel);
+  return true;
+}
+
+static Status pinned_reserve(uint8_t** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap && *p) return Status();
+  if (*p) hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = bytes + bytes / 8 + 4096;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(p), want, hipHostMallocDefault));
+  *cap = want;
+  return Status();
+}
+
+static Status emit_on_device(evql_query* q, EmitArgs& ea, const uint64_t* d_rec, uint64_t n,
+                             uint32_t nwords) {
+  evql_table* t = q->table;
+  const KernelPlan& kp = q->rplan();
+  hipStream_t s = q->ctx->stream;
+  const uint32_t nsel = ea.ncols;
+  evql_query::DeviceEmit& de = q->demit;
+  de.col.resize(nsel, nullptr);
+  de.col_cap.resize(nsel, 0);
+  de.off.resize(nsel, nullptr);
+  de.off_cap.resize(nsel, 0);
+  de.elem.assign(nsel, 0);
+  ea.records = d_rec;
+  ea.n = n;
+  ea.rw = nwords + 1;
+  ea.image = t->d_image;
+  bool need_first = false;
+  for (uint32_t i = 0; i < nsel; ++i) need_first = need_first || ea.col[i].kind == 2;
+  DevBuf<uint64_t> d_rows, d_vals;
+  DevBuf<uint8_t> d_tags;
+  DevBuf<RtColumn> d_cols;
+  const uint32_t nc = uint32_t(kp.cols.size());
+  if (need_first) {
+    // the column values of every group's first row (strings: their strpos words)
+    std::vector<RtColumn> rc(nc);
+    for (uint32_t c = 0; c < nc; ++c) {
+      const ColAccess& ca = kp.cols[c];
+      rc[c] = RtColumn{};
+      rc[c].pages = ca.layout_index >= 0 ? t->d_pages[ca.layout_index][0] : nullptr;
+      rc[c].mode = ca.mode;
+      rc[c].bits = ca.bits;
+      if (ca.packed) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].pages = m.d_packed_pages;
+        rc[c].base = m.d_packed;
+      } else if (ca.mode == ColAccess::SOA) {
+        const MaterializedColumn& m = t->materialized[ca.name];
+        rc[c].soa = ca.string_hash ? m.d_strpos : m.d_values;
+        rc[c].tags = m.d_tags;
+      }
+    }
+    HIP_TRY(d_rows.alloc(n * 8));
+    HIP_TRY(d_cols.alloc(nc * sizeof(RtColumn)));
+    HIP_TRY(d_vals.alloc(n * nc * 8));
+    HIP_TRY(d_tags.alloc(n * nc));
+    HIP_TRY(launch_extract_word(d_rec, n, nwords + 1, uint32_t(1 + kp.first_row_word()), d_rows, s));
+    HIP_TRY(hipMemcpyAsync(d_cols, rc.data(), nc * sizeof(RtColumn), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_gather_rows(t->d_image, d_cols, nc, d_rows, n, d_vals, d_tags, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (rc lives until here)
+    ea.first_vals = d_vals;
+    ea.first_tags = d_tags;
+  }
+  // device buffers of the packed columns
+  std::vector<DevBuf<uint8_t>> d_out(nsel);
+  std::vector<DevBuf<uint64_t>> d_off(nsel);
+  std::vector<uint64_t> str_bytes(nsel, 0);
+  DevBuf<EmitArgs> d_args;
+  HIP_TRY(d_args.alloc(sizeof(EmitArgs)));
+  for (uint32_t i = 0; i < nsel; ++i) {
+    EmitCol& e = ea.col[i];
+    de.elem[i] = e.elem;
+    if (e.elem) {
+      HIP_TRY(d_out[i].alloc(n * e.elem));
+      e.out = d_out[i];
+    } else {
+      e.pages = t->d_pages[kp.cols[e.src].layout_index][0];
+      HIP_TRY(d_off[i].alloc((n + 2) * 8));
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(d_args, &ea, sizeof(EmitArgs), hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_emit_fixed(d_args, n, s));
+  bool strings = false;
+  for (uint32_t i = 0; i < nsel; ++i) {
+    if (ea.col[i].elem) continue;
+    strings = true;
+    HIP_TRY(launch_emit_str_sizes(d_args, i, n, d_off[i], s));
+    HIP_TRY(launch_exclusive_scan(d_off[i], n, d_off[i].p + n, s));
+    HIP_TRY(hipMemcpyAsync(&str_bytes[i], d_off[i].p + n, 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (strings) {
+    for (uint32_t i = 0; i < nsel; ++i) {
+      if (ea.col[i].elem) continue;
+      HIP_TRY(d_out[i].alloc(str_bytes[i] + 16));
+      ea.col[i].out = d_out[i];
+      ea.col[i].offsets = d_off[i];
+    }
+    HIP_TRY(hipMemcpyAsync(d_args, &ea, sizeof(EmitArgs), hipMemcpyHostToDevice, s));
+    for (uint32_t i = 0; i < nsel; ++i) {
+      if (!ea.col[i].elem) HIP_TRY(launch_emit_str_bytes(d_args, i, n, s));
+    }
+  }
+  // one copy per column into pinned host memory
+  for (uint32_t i = 0; i < nsel; ++i) {
+    const size_t bytes = ea.col[i].elem ? size_t(n) * ea.col[i].elem : size_t(str_bytes[i]);
+    Status st = pinned_reserve(&de.col[i], &de.col_cap[i], bytes);
+    if (!st.ok()) return st;
+    if (bytes) HIP_TRY(hipMemcpyAsync(de.col[i], d_out[i], bytes, hipMemcpyDeviceToHost, s));
+    if (!ea.col[i].elem) {
+      uint8_t* po = reinterpret_cast<uint8_t*>(de.off[i]);
+      st = pinned_reserve(&po, &de.off_cap[i], (n + 1) * 8);
+      de.off[i] = reinterpret_cast<uint64_t*>(po);
+      if (!st.ok()) return st;
+      HIP_TRY(hipMemcpyAsync(de.off[i], d_off[i], (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  de.active = true;
+  return Status();
+}
+
 static Status fetch_results(evql_query* q) {
   evql_ctx* ctx = q->ctx;
   evql_table* t = q->table;
@@ -2253,6 +2447,21 @@ static Status fetch_results(evql_query* q) {
   }
   q->ngroups = n;
   q->rec_stride = nwords + 1;
+  q->demit.active = false;
+  if (n >= kDeviceEmitMinGroups) {
+    EmitArgs ea{};
+    if (device_emit_columns(q, merged, &ea)) {
+      Status ste = emit_on_device(q, ea, d_rec, n, nwords);
+      if (!ste.ok()) return ste;
+      q->records.clear();
+      q->distinct_values.clear();
+      q->stats.num_groups = total_groups;
+      q->emit_pos = 0;
+      q->executed = true;
+      q->fetched = true;
+      return Status();
+    }
+  }
   q->records.assign(n * (nwords + 1), 0);
   if (n) {
     HIP_TRY(hipMemcpyAsync(q->records.data(), d_rec, n * (nwords + 1) * 8,
@@ -2700,6 +2909,25 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
     if (!st.ok()) return st;
     st = order_fetched(q);
     if (!st.ok()) return st;
+  }
+  if (q->demit.active) {
+    // slices of the columns packed on the device (emit_on_device)
+    const evql_query::DeviceEmit& de = q->demit;
+    const uint64_t left = q->ngroups - q->emit_pos;
+    const uint64_t m = std::min<uint64_t>(left, max_rows);
+    for (size_t i = 0; i < de.col.size(); ++i) {
+      if (de.elem[i]) {
+        cols[i].data = de.col[i] + q->emit_pos * de.elem[i];
+        cols[i].size = size_t(m) * de.elem[i];
+      } else {
+        const uint64_t b0 = de.off[i][q->emit_pos], b1 = de.off[i][q->emit_pos + m];
+        cols[i].data = de.col[i] + b0;
+        cols[i].size = size_t(b1 - b0);
+      }
+    }
+    q->emit_pos += m;
+    *nrows = size_t(m);
+    return Status();
   }
   const KernelPlan& kp = q->rplan();
   const size_t nsel = q->select.size();

@@ -340,6 +340,16 @@ struct evql_query {
   std::vector<uint64_t> first_str_off;  // [col][group] offset into the heap
   uint64_t emit_pos = 0;
   std::vector<std::vector<uint8_t>> out_cols;
+  // large results packed on the device (runtime.cc emit_on_device): every output column
+  // of ALL groups as SVector bytes in pinned host memory, next_batch hands out slices
+  struct DeviceEmit {
+    bool active = false;
+    std::vector<uint8_t*> col;      // pinned (hipHostMalloc), per select expression
+    std::vector<size_t> col_cap;
+    std::vector<uint32_t> elem;     // bytes per element; 0 = STRING
+    std::vector<uint64_t*> off;     // strings: pinned [n + 1] byte offsets
+    std::vector<size_t> off_cap;
+  } demit;
   // EVQL_MODE_PARTIAL with count_distinct: the distinct values of every group, per
   // aggregate, read back from the HBM pair set; key = (identity, identity 2 | NULL flag)
   std::vector<std::map<std::pair<uint64_t, uint64_t>, std::vector<uint64_t>>> distinct_values;
