@@ -118,6 +118,10 @@ def lib():
     L.evql_query_export_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
     L.evql_query_import_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.evql_query_reset.argtypes = [C.c_void_p]
+    L.evql_query_distinct_aggregates.restype = C.c_uint32
+    L.evql_query_distinct_aggregates.argtypes = [C.c_void_p]
+    L.evql_query_export_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, _u64p]
+    L.evql_query_import_pairs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.evql_query_set_order.argtypes = [C.c_void_p, C.POINTER(K.SortSpec), C.c_uint32, C.c_int64,
                                        C.c_uint64]
     L.evql_lsm_chain_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -441,6 +445,16 @@ class Query:
 
     def import_groups(self, device_ptr, n):
         _check(lib().evql_query_import_groups(self.h, device_ptr, n))
+
+    def export_pairs(self, which, device_ptr, max_pairs):
+        """count_distinct pairs of the which-th such aggregate (3 words each); device_ptr
+        None: the count only"""
+        n = C.c_uint64()
+        _check(lib().evql_query_export_pairs(self.h, which, device_ptr, max_pairs, C.byref(n)))
+        return n.value
+
+    def import_pairs(self, which, device_ptr, n):
+        _check(lib().evql_query_import_pairs(self.h, which, device_ptr, n))
 
     def exchange(self, x, mode=K.EXCHANGE_GATHER_ALL):
         """evql_query_exchange (collective): afterwards next_batch yields the merged

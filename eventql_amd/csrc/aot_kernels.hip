@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(kBlock) k_pairset_merge(PairsetMergeArgs a, co
       atomicOr(&a.status[0], EVQL_ST_PAIRSET_FULL);
       continue;
     }
-    if (!fresh) continue;
+    if (!fresh || !a.words) continue;
     // the group this pair belongs to
     i64 gs;
     if (a.key_mode == 1) {  // exact key: flags = NULL-key bit | escape bits

@@ -24,6 +24,7 @@ size_t lsm_chain_parts(const evql_lsm_chain* ch, std::vector<evql_table*>* table
                        std::vector<const uint8_t*>* d_filters);  // lsm.cc
 evql_ctx* lsm_chain_ctx(const evql_lsm_chain* ch);
 Status query_reserve_groups(evql_query* q, uint64_t extra);
+Status query_import_pairs(evql_query* q, int which, const uint64_t* d_triples, uint64_t n);
 Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n, int64_t limit,
                        uint64_t offset);
 Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols, size_t* nrows);
@@ -766,7 +767,6 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst, uint64_t max_gro
     // another partition may have chosen a different one
     return fail(EVQL_EARG, "exact float sums travel between partitions only with an explicit float_sum_bound");
   }
-  if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   if (q->rplan().need_first_row) {
     // a first-row index means something only inside the table that produced it:
     // the key / select values of such plans travel inside the records of
@@ -806,7 +806,6 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
     // another partition may have chosen a different one
     return fail(EVQL_EARG, "exact float sums travel between partitions only with an explicit float_sum_bound");
   }
-  if (q->kp.n_distinct) return fail(EVQL_ENOTSUP, "count_distinct sets do not travel");
   if (q->rplan().need_first_row) {
     return fail(EVQL_ENOTSUP, "plan reads first-row values: merge it with evql_query_exchange");
   }
@@ -826,6 +825,11 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
   if (q->kp.has_ident2()) a.ops[w++] = 255;
   if (q->kp.need_first_row) a.ops[w++] = 2;  // min
   for (const auto& sw : q->kp.states) a.ops[w++] = uint32_t(sw.op);
+  // a count_distinct word counts the pairs of THIS query's set: foreign counts are not
+  // added, the pairs arrive through evql_query_import_pairs and are counted there
+  for (const auto& ag : q->kp.aggs) {
+    if (ag.distinct_index >= 0) a.ops[q->kp.state_word_base() + ag.first_word] = 254;  // no such op: skipped
+  }
   a.status = q->d_status;
   hipMemsetAsync(q->d_status, 0, 16, s);
   hipError_t e = launch_table_merge(a, static_cast<const uint64_t*>(device_src), n_groups, s);
@@ -843,6 +847,42 @@ int evql_query_import_groups(evql_query_t* q, const void* device_src, uint64_t n
   }
   // the host copy of the result (if any) is stale now
   return ret(query_recount(q));
+  API_CATCH
+}
+
+uint32_t evql_query_distinct_aggregates(const evql_query_t* q) { return q ? uint32_t(q->kp.n_distinct) : 0; }
+
+int evql_query_export_pairs(evql_query_t* q, uint32_t which, void* device_dst, uint64_t max_pairs,
+                            uint64_t* n_pairs) {
+  API_TRY
+  if (!q || !n_pairs) return fail(EVQL_EARG, "null argument");
+  if (which >= uint32_t(q->kp.n_distinct)) return fail(EVQL_EARG, "no such count_distinct aggregate");
+  if (q->merged) return fail(EVQL_EARG, "the query's groups were merged (exchange / chain): emit them with next_batch");
+  hipStream_t s = q->ctx->stream;
+  *n_pairs = 0;
+  if (!q->d_pairset[which]) return EVQL_OK;  // (nothing scanned yet: an empty merge target)
+  uint64_t* d_cnt = q->d_counters + 6;
+  hipMemsetAsync(d_cnt, 0, 8, s);
+  hipError_t e = launch_pairset_export(q->d_pairset[which], q->pairset_cap,
+                                       static_cast<uint64_t*>(device_dst), device_dst ? max_pairs : 0,
+                                       d_cnt, s);
+  uint64_t n = 0;
+  hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return fail(EVQL_EDEVICE, "export kernel failed");
+  *n_pairs = n;  // (device_dst == NULL: the count only)
+  if (device_dst && n > max_pairs) return fail(EVQL_ENOMEM, "export buffer too small");
+  return EVQL_OK;
+  API_CATCH
+}
+
+int evql_query_import_pairs(evql_query_t* q, uint32_t which, const void* device_src,
+                            uint64_t n_pairs) {
+  API_TRY
+  if (!q || (!device_src && n_pairs)) return fail(EVQL_EARG, "null argument");
+  if (which >= uint32_t(q->kp.n_distinct)) return fail(EVQL_EARG, "no such count_distinct aggregate");
+  if (q->merged) return fail(EVQL_EARG, "the query's groups were merged (exchange / chain): emit them with next_batch");
+  if (!q->d_gtab) return fail(EVQL_EARG, "import the group records first");
+  return ret(query_import_pairs(q, int(which), static_cast<const uint64_t*>(device_src), n_pairs));
   API_CATCH
 }
 

@@ -243,7 +243,7 @@ static Status exchange_pairset(evql_query* q, evql_exchange* x, bool by_owner, i
   }
   HIP_TRY(hipMemcpyAsync(&np, d_cnt, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  WsBuf<uint64_t> d_tr(x, 11), d_send(x, 12), d_aux(x, 4), d_recv(x, 13), d_set(x, 14);
+  WsBuf<uint64_t> d_tr(x, 11), d_send(x, 12), d_aux(x, 4), d_recv(x, 13);
   HIP_TRY(d_tr.alloc(std::max<uint64_t>(np, 1) * 24));
   if (np) {
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
@@ -291,7 +291,17 @@ static Status exchange_pairset(evql_query* q, evql_exchange* x, bool by_owner, i
   x->stats.bytes_sent += (by_owner ? np : np * uint64_t(N - 1)) * 24;
   uint64_t set_cap = 1024;
   while (set_cap < total * 2) set_cap <<= 1;
-  HIP_TRY(d_set.alloc(set_cap * 24));
+  // the merged set belongs to the query: EVQL_MODE_PARTIAL rows carry the values of every
+  // group's set (aggregate.cc:111-117), read back from here at emission
+  if (q->d_mset[which] && q->mset_cap[which] != set_cap) {
+    hipFree(q->d_mset[which]);
+    q->d_mset[which] = nullptr;
+  }
+  if (!q->d_mset[which]) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mset[which]), set_cap * 24));
+  }
+  q->mset_cap[which] = set_cap;
+  uint64_t* d_set = q->d_mset[which];
   HIP_TRY(hipMemsetAsync(d_set, 0xff, set_cap * 24, s));
   PairsetMergeArgs pa{};
   pa.set = d_set;
@@ -316,9 +326,6 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   const KernelPlan& kp = q->rplan();
   const int N = x->nranks;
   if (!q->executed) return Status::error(EVQL_EARG, "execute() was not called");
-  if (kp.n_distinct && q->group_mode == EVQL_MODE_PARTIAL) {
-    return Status::error(EVQL_ENOTSUP, "count_distinct in a partial aggregate travels as wire rows");
-  }
   if (N > int(kMaxExchangeRanks)) return Status::error(EVQL_EARG, "too many ranks");
   if (q->merged) return Status::error(EVQL_EARG, "the query was exchanged already");
   const uint32_t W = uint32_t(kp.words_per_slot());
@@ -893,7 +900,7 @@ Status chain_merge(evql_query* head) {
       const int d = ag.distinct_index;
       uint64_t tot = 0;
       for (size_t pi = 0; pi < parts.size(); ++pi) tot += counts[size_t(d) * parts.size() + pi];
-      DevBuf<uint64_t> d_tr, d_set;
+      DevBuf<uint64_t> d_tr;
       HIP_TRY(d_tr.alloc(std::max<uint64_t>(tot, 1) * 24));
       uint64_t off = 0;
       for (size_t pi = 0; pi < parts.size(); ++pi) {
@@ -905,7 +912,15 @@ Status chain_merge(evql_query* head) {
         HIP_TRY(launch_pairset_export(q->d_pairset[d], q->pairset_cap, d_tr.p + off * 3, np, d_cnt, s));
         off += np;
       }
-      HIP_TRY(d_set.alloc(set_cap * 24));
+      if (head->d_mset[d] && head->mset_cap[d] != set_cap) {
+        hipFree(head->d_mset[d]);
+        head->d_mset[d] = nullptr;
+      }
+      if (!head->d_mset[d]) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&head->d_mset[d]), set_cap * 24));
+      }
+      head->mset_cap[d] = set_cap;
+      uint64_t* d_set = head->d_mset[d];
       HIP_TRY(hipMemsetAsync(d_set, 0xff, set_cap * 24, s));
       PairsetMergeArgs pa{};
       pa.set = d_set;
@@ -918,12 +933,9 @@ Status chain_merge(evql_query* head) {
       pa.status = head->d_status;
       HIP_TRY(launch_pairset_merge(pa, d_tr, tot, s));
       HIP_TRY(hipStreamSynchronize(s));
-      // the merged set replaces the head's own: PARTIAL emission reads the values of
-      // every group from it (fetch_results)
-      if (head->d_pairset[d]) hipFree(head->d_pairset[d]);
-      head->d_pairset[d] = d_set.release();
+      // (PARTIAL emission reads the values of every group from the merged set,
+      // fetch_results)
     }
-    head->pairset_cap = set_cap;
   }
   uint32_t status[4] = {0};
   HIP_TRY(hipMemcpyAsync(status, head->d_status, 16, hipMemcpyDeviceToHost, s));

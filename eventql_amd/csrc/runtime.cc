@@ -1,6 +1,7 @@
 // runtime.cc -- HIP device context, table residency in HBM, JIT of the fused
 // kernel, execution and result emission.
 #include "runtime.h"
+#include <dlfcn.h>
 #include <unistd.h>
 #include <atomic>
 #include <algorithm>
@@ -18,6 +19,24 @@ namespace evql {
 
 static thread_local std::string g_last_error;
 static std::string g_cache_dir;
+static bool g_cache_dir_set = false;
+
+// Default place of the on-disk kernel cache: `_kcache` next to this shared library (the
+// directory the python package points evql_set_kernel_cache_dir at too), so that every
+// host of the library -- the adapter inside evqld, the probe, python -- shares the
+// compiled plan kernels.  evql_set_kernel_cache_dir("") switches the disk cache off.
+static const std::string& cache_dir() {
+  if (!g_cache_dir_set) {
+    g_cache_dir_set = true;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&cache_dir), &info) && info.dli_fname) {
+      std::string path = info.dli_fname;
+      const size_t slash = path.rfind('/');
+      g_cache_dir = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/_kcache";
+    }
+  }
+  return g_cache_dir;
+}
 
 void set_last_error(const std::string& m) { g_last_error = m; }
 const std::string& last_error() { return g_last_error; }
@@ -25,7 +44,10 @@ int fail(int code, const std::string& m) {
   g_last_error = m;
   return code;
 }
-void set_cache_dir(const std::string& d) { g_cache_dir = d; }
+void set_cache_dir(const std::string& d) {
+  g_cache_dir = d;
+  g_cache_dir_set = true;
+}
 
 #define HIP_TRY(expr)                                                             \
   do {                                                                            \
@@ -65,8 +87,9 @@ Status compile_to_code_object(const std::string& source, std::vector<char>* code
   const std::string full = std::string(device_library_source()) + "\n" + source;
   std::string key = hex_digest(full);
   std::string cache_file;
-  if (!g_cache_dir.empty()) {
-    cache_file = g_cache_dir + "/" + key + ".hsaco";
+  const std::string& dir = cache_dir();
+  if (!dir.empty()) {
+    cache_file = dir + "/" + key + ".hsaco";
     std::ifstream f(cache_file, std::ios::binary);
     if (f && use_cache) {
       code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -95,7 +118,7 @@ Status compile_to_code_object(const std::string& source, std::vector<char>* code
   hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
   if (!cache_file.empty()) {
-    mkdir(g_cache_dir.c_str(), 0755);
+    mkdir(dir.c_str(), 0755);
     // (several processes -- one per GPU -- compile the same plan at the same time: each
     // writes a file of its own and renames it into place)
     static std::atomic<unsigned> serial{0};
@@ -280,6 +303,9 @@ evql_query::~evql_query() {
   if (d_counters) hipFree(d_counters);
   if (d_small_rec) hipFree(d_small_rec);
   for (auto* p : d_pairset) {
+    if (p) hipFree(p);
+  }
+  for (auto* p : d_mset) {
     if (p) hipFree(p);
   }
   if (d_row_filter && row_filter_owned) hipFree(d_row_filter);
@@ -2121,6 +2147,87 @@ Status query_reserve_groups(evql_query* q, uint64_t extra) {
   return rebuild_table(q, q->ngroups + extra);
 }
 
+// count_distinct pairs of another partition into this query's set (aggregate.cc:119-137:
+// mergeInstance inserts the other set's values); every pair that is new adds 1 to its
+// group's aggregate.  The set is regrown first when the pairs might not fit.
+Status query_import_pairs(evql_query* q, int which, const uint64_t* d_triples, uint64_t n) {
+  hipStream_t s = q->ctx->stream;
+  const KernelPlan& kp = q->kp;
+  if (q->dense_n) {
+    Status st = query_dense_into_table(q);
+    if (!st.ok()) return st;
+  }
+  // pairs held today (all sets share one capacity: the scan kernel takes one)
+  uint64_t held_max = 0;
+  std::vector<uint64_t> held(kp.n_distinct, 0);
+  for (int d = 0; d < kp.n_distinct; ++d) {
+    if (!q->d_pairset[d]) continue;
+    uint64_t* d_cnt = q->d_counters + 6;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+    HIP_TRY(launch_pairset_export(q->d_pairset[d], q->pairset_cap, nullptr, 0, d_cnt, s));
+    HIP_TRY(hipMemcpyAsync(&held[d], d_cnt, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    held_max = std::max(held_max, held[d]);
+  }
+  const uint64_t need = std::max(held_max, held[which] + n);
+  uint64_t cap = q->pairset_cap ? q->pairset_cap : (1 << 16);
+  while (cap < need * 2) cap <<= 1;
+  if (cap != q->pairset_cap) {
+    // regrow every set: stored triples re-inserted as they are, nothing counted again
+    for (int d = 0; d < kp.n_distinct; ++d) {
+      DevBuf<uint64_t> d_new, d_tr;
+      HIP_TRY(d_new.alloc(cap * 24));
+      HIP_TRY(hipMemsetAsync(d_new, 0xff, cap * 24, s));
+      if (q->d_pairset[d] && held[d]) {
+        HIP_TRY(d_tr.alloc(held[d] * 24));
+        uint64_t* d_cnt = q->d_counters + 6;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+        HIP_TRY(launch_pairset_export(q->d_pairset[d], q->pairset_cap, d_tr, held[d], d_cnt, s));
+        PairsetMergeArgs pa{};
+        pa.set = d_new;
+        pa.set_cap = cap;
+        pa.words = nullptr;
+        pa.status = q->d_status;
+        HIP_TRY(launch_pairset_merge(pa, d_tr, held[d], s));
+        HIP_TRY(hipStreamSynchronize(s));
+      }
+      if (q->d_pairset[d]) hipFree(q->d_pairset[d]);
+      q->d_pairset[d] = d_new.release();
+    }
+    q->pairset_cap = cap;
+  }
+  for (int d = 0; d < kp.n_distinct; ++d) {
+    if (q->d_pairset[d]) continue;  // (an empty merge target: evql_query_reset)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_pairset[d]), q->pairset_cap * 24));
+    HIP_TRY(hipMemsetAsync(q->d_pairset[d], 0xff, q->pairset_cap * 24, s));
+  }
+  if (n == 0) return Status();
+  int word = -1;
+  for (const auto& ag : kp.aggs) {
+    if (ag.distinct_index == which) word = kp.state_word_base() + ag.first_word;
+  }
+  PairsetMergeArgs pa{};
+  pa.set = q->d_pairset[which];
+  pa.set_cap = q->pairset_cap;
+  pa.words = q->d_gtab;
+  pa.gcap = q->gcap;
+  pa.nwords = uint32_t(kp.words_per_slot());
+  pa.word = uint32_t(word);
+  pa.key_mode = uint32_t(kp.key_mode);
+  pa.status = q->d_status;
+  HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
+  HIP_TRY(launch_pairset_merge(pa, d_triples, n, s));
+  uint32_t status[4] = {0};
+  HIP_TRY(hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (status[0] & 8u) return Status::error(EVQL_ENOMEM, "count_distinct set full");
+  if (status[0] & 2u) {
+    return Status::error(EVQL_EARG, "a pair's group is not in the table: import the group records first");
+  }
+  q->fetched = false;
+  return Status();
+}
+
 // (re)creates an empty group table without scanning: the merge target of
 // GroupByMergeExpression (groupby.cc:528-637)
 Status query_reset(evql_query* q) {
@@ -2589,12 +2696,15 @@ static Status fetch_results(evql_query* q) {
   if (q->group_mode == EVQL_MODE_PARTIAL && kp.n_distinct > 0) {
     // count_distinct's saved state is the set itself (aggregate.cc:111-117): the
     // (group, value, flags) triples of the aggregate's pair set, grouped on the host
-    const uint64_t cap = q->pairset_cap;
     const bool hashed = kp.key_mode == KEY_HASHED;
     q->distinct_values.resize(kp.n_distinct);
-    std::vector<uint64_t> host(cap * 3);
+    std::vector<uint64_t> host;
     for (int d = 0; d < kp.n_distinct; ++d) {
-      HIP_TRY(hipMemcpy(host.data(), q->d_pairset[d], cap * 3 * 8, hipMemcpyDeviceToHost));
+      // (merged results: the union of the ranks' / tables' sets, exchange.cc)
+      const uint64_t cap = merged ? q->mset_cap[d] : q->pairset_cap;
+      const uint64_t* d_set = merged ? q->d_mset[d] : q->d_pairset[d];
+      host.assign(cap * 3, ~0ull);
+      if (d_set && cap) HIP_TRY(hipMemcpy(host.data(), d_set, cap * 3 * 8, hipMemcpyDeviceToHost));
       auto& sets = q->distinct_values[d];
       for (uint64_t sl = 0; sl < cap; ++sl) {
         uint64_t ident = host[sl], value = host[cap + sl], flags = host[2 * cap + sl];

@@ -317,6 +317,10 @@ struct evql_query {
   // count_distinct pair sets (3 word planes of pairset_cap slots each)
   uint64_t* d_pairset[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t pairset_cap = 0;
+  // after an exchange / chain merge: the merged pair sets (the union of the ranks' /
+  // tables' sets for the groups this query now holds); PARTIAL rows read their values here
+  uint64_t* d_mset[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t mset_cap[4] = {0, 0, 0, 0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool probed = false;    // cardinality probe done (plans without groups_hint)
   bool keep_table = false;  // launch without emptying the group table / counters (the

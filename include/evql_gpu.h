@@ -156,9 +156,10 @@ typedef enum {
   EVQL_AGG_MEAN_INT64 = 12,
   EVQL_AGG_MEAN_FLOAT64 = 13,
   /* count_distinct#uint64/uint64; (aggregate.cc:77-137, std::set per group):
-   * exact, on one device (HBM set of (group, value) pairs); EVQL_ENOTSUP in
-   * EVQL_MODE_PARTIAL and for evql_query_export/import_groups -- the sets do not
-   * travel between devices.  evql_merge_* merges its wire states. */
+   * exact (HBM set of (group, value) pairs).  The pairs follow their groups through
+   * evql_query_exchange and chain merges; evql_query_export_pairs / _import_pairs move them
+   * for callers of export / import_groups; EVQL_MODE_PARTIAL rows carry the sorted values
+   * (aggregate.cc:111-117), which evql_merge_* merges. */
   EVQL_AGG_COUNT_DISTINCT_UINT64 = 14
 } evql_aggregate_fn;
 
@@ -531,10 +532,22 @@ int evql_query_export_groups(evql_query_t* q, void* device_dst,
  * is regrown first when the incoming groups would not fit.  Both answer EVQL_ENOTSUP
  * for plans whose records name a first ROW (string / multi-column keys, non-aggregate
  * select expressions) -- a row index means nothing outside the table that produced
- * it; evql_query_exchange carries the values themselves -- and for count_distinct. */
+ * it; evql_query_exchange carries the values themselves.  count_distinct: see
+ * evql_query_export_pairs. */
 int evql_query_import_groups(evql_query_t* q, const void* device_src,
                              uint64_t n_groups);
 uint32_t evql_query_record_words(const evql_query_t* q);
+/* count_distinct (aggregate.cc:77-137: a std::set per group, merged by insertion) for
+ * callers that move partial aggregates themselves: the stored (group, value) pairs of the
+ * plan's `which`-th count_distinct aggregate as 3-word triples.  _import_pairs inserts them
+ * into this query's set and adds 1 to the aggregate of every group a pair is new to; call
+ * it AFTER evql_query_import_groups of the records the pairs belong to (import_groups
+ * leaves count_distinct words alone: the counts follow from the pairs). */
+uint32_t evql_query_distinct_aggregates(const evql_query_t* q);
+int evql_query_export_pairs(evql_query_t* q, uint32_t which, void* device_dst,
+                            uint64_t max_pairs, uint64_t* n_pairs);
+int evql_query_import_pairs(evql_query_t* q, uint32_t which, const void* device_src,
+                            uint64_t n_pairs);
 /* empties the query's group table without scanning, so that it can serve as the
  * merge target of partial aggregates (GroupByMergeExpression, groupby.cc:528-637) */
 int evql_query_reset(evql_query_t* q);
@@ -607,7 +620,8 @@ typedef enum {
  * records: the first row of the lowest rank that has the group wins, strings travel
  * as bytes.  next_batch then yields the merged groups.  count_distinct: the (group,
  * value) pairs follow their groups and are counted again in the merged set
- * (aggregate.cc:119-137); EVQL_ENOTSUP only together with EVQL_MODE_PARTIAL.
+ * (aggregate.cc:119-137), also for EVQL_MODE_PARTIAL plans (their rows then carry the
+ * merged sets' values).
  */
 int evql_query_exchange(evql_query_t* q, evql_exchange_t* x, int mode);
 
@@ -736,6 +750,9 @@ int evql_query_create_chain(evql_ctx_t* ctx, evql_lsm_chain_t* ch,
 int evql_compile_only(const evql_plan_desc_t* plan,
                       const evql_column_info_t* columns, int ncolumns,
                       const char* cache_dir, size_t* code_size);
+/* on-disk cache of the compiled plan kernels (code objects named by the fingerprint of
+ * their source).  Default: the directory `_kcache` next to this shared library, shared by
+ * every process that loads it; "" switches the disk cache off. */
 void evql_set_kernel_cache_dir(const char* dir);
 
 #ifdef __cplusplus

@@ -11,10 +11,13 @@
  *   - decode half: checked against the reference's own cstable library
  *     compiled in place (oracle/_ref, `make ref`) and against
  *     test/sql_testdata/testtbl.cst
- *   - csql half: the reference's csql layer needs protoc-generated headers and
- *     is not buildable here; pinned by the reference's test fixtures
- *     (test/sql/00001,00002,00014; Runtime_test.cc known answers) and by the
- *     reference outputs recorded in SURVEY.md section 8c(ii)/8a.
+ *   - csql half: checked against the reference's own csql engine compiled in place
+ *     (oracle/ref_csql/build.sh -> oracle/_ref/csql_probe): results, PartialGroupBy
+ *     bytes and compiled bytecode of 426 queries incl. GROUP BYs over
+ *     eventql::PartitionCursor, committed as tests/golden/ref_csql_*.json; plus the
+ *     reference's test fixtures (test/sql/00001,00002,00014; Runtime_test.cc)
+ *   - unpinned (absent from this snapshot of the reference): sum(float64), min, max,
+ *     mean; WITHIN RECORD beyond the three Runtime_test.cc answers
  */
 #ifndef EVQL_ORACLE_H
 #define EVQL_ORACLE_H

@@ -321,3 +321,22 @@ def test_wide_first_row_plan_is_refused_before_anything_is_written(ctx):
     x.close()
     hub.close()
     t.close()
+
+
+@pytest.mark.parametrize("name", ["distinct-u64-key", "distinct-string-key", "distinct-global"])
+def test_partial_rows_with_count_distinct_after_an_exchange(name):
+    """EVQL_MODE_PARTIAL + count_distinct through the device exchange: the pair sets follow
+    their groups, and the PartialGroupByExpression rows emitted afterwards carry the MERGED
+    sets' values (varuint size + ascending values, aggregate.cc:111-117) -- byte for byte
+    what the oracle's partial operator emits over the concatenated partitions"""
+    kw = dict(PLANS[name])
+    kw.pop("key_cols", None)
+    parts = [partition(300 + r, 20_000 + 3000 * r) for r in range(3)]
+    pkw = dict(kw, mode=K.MODE_PARTIAL)
+    ep = O.oracle_run(image_of(parts), Plan(S, **pkw))
+    want = sorted((ep.keys[20 * i:20 * i + 20], ep.columns[0][i]) for i in range(ep.nrows))
+    res = run_ranks(3, parts, pkw, K.EXCHANGE_GATHER_ALL)
+    for rows, _, _ in res:
+        assert sorted(rows) == want
+    res = run_ranks(3, parts, pkw, K.EXCHANGE_BY_OWNER)
+    assert sorted(r for rows, _, _ in res for r in rows) == want

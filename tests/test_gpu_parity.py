@@ -437,6 +437,59 @@ def test_import_grows_the_group_table(mixed):
         q.close()
 
 
+def test_count_distinct_through_export_and_import(mixed):
+    """callers that move partial aggregates themselves (evql_query_export / import_groups):
+    count_distinct travels as its (group, value) pairs (evql_query_export_pairs /
+    _import_pairs) and is counted again in the target's set -- 6 row slices merged into the
+    first one and into an empty `reset` target, against the oracle on the whole table"""
+    import torch
+    from eventql_amd.plan import count_distinct as cd
+    t, img, _ = mixed
+    n, parts = 300_000, 6
+    kw = dict(select=[col("k"), cd(col("a") % 977), count(1), cd(col("b")), sum_(col("a"))],
+              group_by=[col("k")])
+    exp = O.oracle_run(img, Plan(T.MIXED_SCHEMA, **kw))
+    cut = [n * i // parts for i in range(parts + 1)]
+    qs = [t.query(Plan(T.MIXED_SCHEMA, row_begin=cut[i], row_end=cut[i + 1], groups_hint=1000, **kw))
+          for i in range(parts)]
+    for q in qs:
+        q.execute()
+    assert lib_distinct(qs[0]) == 2
+    rw = qs[0].record_words()
+    buf = torch.zeros(4096 * rw, dtype=torch.int64, device="cuda")
+    target = t.query(Plan(T.MIXED_SCHEMA, groups_hint=1000, **kw))
+    target.reset()
+    for q in qs[1:]:
+        cnt = q.export_groups(buf.data_ptr(), 4096)
+        qs[0].import_groups(buf.data_ptr(), cnt)
+        for which in range(2):
+            npairs = q.export_pairs(which, None, 0)
+            pbuf = torch.zeros(max(1, npairs) * 3, dtype=torch.int64, device="cuda")
+            assert q.export_pairs(which, pbuf.data_ptr(), npairs) == npairs
+            qs[0].import_pairs(which, pbuf.data_ptr(), npairs)
+    fresh = [t.query(Plan(T.MIXED_SCHEMA, row_begin=cut[i], row_end=cut[i + 1], groups_hint=1000, **kw))
+             for i in range(parts)]
+    for q in fresh:
+        q.execute()
+        cnt = q.export_groups(buf.data_ptr(), 4096)
+        target.import_groups(buf.data_ptr(), cnt)
+        for which in range(2):
+            npairs = q.export_pairs(which, None, 0)
+            pbuf = torch.zeros(max(1, npairs) * 3, dtype=torch.int64, device="cuda")
+            q.export_pairs(which, pbuf.data_ptr(), npairs)
+            target.import_pairs(which, pbuf.data_ptr(), npairs)
+    for dst in (qs[0], target):
+        got = dst.fetch_all(1 << 20)
+        assert got.nrows == exp.nrows
+        T.compare_results(got.rows(), exp.rows(), exp.types)
+    for q in qs + fresh + [target]:
+        q.close()
+
+
+def lib_distinct(q):
+    return E.lib().evql_query_distinct_aggregates(q.h)
+
+
 def test_partial_group_by_wire_rows(mixed):
     """EVQL_MODE_PARTIAL = PartialGroupByExpression::nextBatch (groupby.cc:438-472):
     (SHA1 group key, concatenated saved states / encoded SValues), byte for byte"""
@@ -582,15 +635,7 @@ def test_count_distinct(mixed):
     check(t, img, select=[col("s"), cd(a % 100)], group_by=[col("s")])  # string key
     check(t, img, select=[b, cd(k)], group_by=[b], groups_hint=70000)   # 65,536 groups
     check(t, img, select=[k, cd(w) + count(1)], group_by=[k])           # post-aggregate arithmetic
-    # the sets stay on one device
-    q = t.query(Plan(T.MIXED_SCHEMA, select=[k, cd(a)], group_by=[k]))
-    q.execute()
-    import torch
-    buf = torch.zeros(4096 * q.record_words(), dtype=torch.int64, device="cuda")
-    with pytest.raises(E.EvqlError) as ei:
-        q.export_groups(buf.data_ptr(), 4096)
-    assert ei.value.code == K.EVQL_ENOTSUP
-    q.close()
+    # (the sets travel as pairs: test_count_distinct_through_export_and_import)
     # PartialGroupBy rows carry the set itself: varuint size, values ascending
     # (aggregate.cc:111-117) -- byte for byte the oracle's (pinned on the reference's
     # bytes in test_gpu_ref_csql.py)
