@@ -14,6 +14,7 @@
 #include <eventql/sql/expressions/boolean.h>
 #include <eventql/sql/expressions/conversion.h>
 #include <eventql/sql/expressions/math.h>
+#include <eventql/sql/expressions/string.h>
 
 namespace evql_adapter {
 namespace ex = csql::expressions;
@@ -86,6 +87,25 @@ const PureEntry kPure[] = {
      "to_timestamp64#timestamp64/int64;"},
     {&ex::to_timestamp64_float64, EVQL_FN(EVQL_FAM_TO_TIMESTAMP64, EVQL_TS_FLOAT64),
      "to_timestamp64#timestamp64/float64;"},
+    /* strings: conversion.cc:140-215, expressions/string.cc (select-list only; evaluated
+     * by the library on the host at emission).  to_string_timestamp64 shares
+     * to_string_uint64's call pointer: whichever entry matches first yields the same
+     * bytes (both print the decimal value) */
+    {&ex::to_string_nil, EVQL_FN(EVQL_FAM_TO_STRING, EVQL_TS_NIL), "to_string#string/nil;"},
+    {&ex::to_string_uint64, EVQL_FN(EVQL_FAM_TO_STRING, EVQL_TS_UINT64), "to_string#string/uint64;"},
+    {&ex::to_string_int64, EVQL_FN(EVQL_FAM_TO_STRING, EVQL_TS_INT64), "to_string#string/int64;"},
+    {&ex::to_string_float64, EVQL_FN(EVQL_FAM_TO_STRING, EVQL_TS_FLOAT64),
+     "to_string#string/float64;"},
+    {&ex::to_string_bool, EVQL_FN(EVQL_FAM_TO_STRING, EVQL_TS_BOOL), "to_string#string/bool;"},
+    {&ex::concat, EVQL_FN(EVQL_FAM_CONCAT, EVQL_TS_STRING), "concat#string/string;string;"},
+    {&ex::lcase, EVQL_FN(EVQL_FAM_LCASE, EVQL_TS_STRING), "lcase#string/string;"},
+    {&ex::ucase, EVQL_FN(EVQL_FAM_UCASE, EVQL_TS_STRING), "ucase#string/string;"},
+    {&ex::substring, EVQL_FN(EVQL_FAM_SUBSTRING, EVQL_TS_STRING), "substring#string/string;int64;"},
+    {&ex::ltrim, EVQL_FN(EVQL_FAM_LTRIM, EVQL_TS_STRING), "ltrim#string/string;"},
+    {&ex::rtrim, EVQL_FN(EVQL_FAM_RTRIM, EVQL_TS_STRING), "rtrim#string/string;"},
+    {&ex::startswith, EVQL_FN(EVQL_FAM_STARTSWITH, EVQL_TS_STRING),
+     "startswith#bool/string;string;"},
+    {&ex::endswith, EVQL_FN(EVQL_FAM_ENDSWITH, EVQL_TS_STRING), "endswith#bool/string;string;"},
 };
 
 struct AggEntry {

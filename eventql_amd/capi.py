@@ -38,7 +38,8 @@ TS_UINT64, TS_INT64, TS_FLOAT64, TS_BOOL, TS_STRING, TS_TIMESTAMP64, TS_NIL = \
     range(7)
 (FAM_LOGICAL_AND, FAM_LOGICAL_OR, FAM_NEG, FAM_CMP, FAM_EQ, FAM_NEQ, FAM_LT,
  FAM_LTE, FAM_GT, FAM_GTE, FAM_ADD, FAM_SUB, FAM_MUL, FAM_DIV, FAM_MOD, FAM_POW,
- FAM_TO_NIL, FAM_TO_INT64, FAM_TO_TIMESTAMP64) = range(1, 20)
+ FAM_TO_NIL, FAM_TO_INT64, FAM_TO_TIMESTAMP64, FAM_TO_STRING, FAM_CONCAT, FAM_LCASE, FAM_UCASE,
+ FAM_SUBSTRING, FAM_LTRIM, FAM_RTRIM, FAM_STARTSWITH, FAM_ENDSWITH) = range(1, 29)
 
 
 def FN(family, type_slot):

@@ -1,4 +1,5 @@
 #include "plan_ir.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <sstream>
@@ -25,6 +26,11 @@ int family_arity(int fam) {
     case EVQL_FAM_TO_NIL:
     case EVQL_FAM_TO_INT64:
     case EVQL_FAM_TO_TIMESTAMP64:
+    case EVQL_FAM_TO_STRING:
+    case EVQL_FAM_LCASE:
+    case EVQL_FAM_UCASE:
+    case EVQL_FAM_LTRIM:
+    case EVQL_FAM_RTRIM:
       return 1;
     default:
       return 2;
@@ -42,7 +48,17 @@ uint32_t call_return_type(int fam, int ts) {
     case EVQL_FAM_LTE:
     case EVQL_FAM_GT:
     case EVQL_FAM_GTE:
+    case EVQL_FAM_STARTSWITH:
+    case EVQL_FAM_ENDSWITH:
       return EVQL_T_BOOL;
+    case EVQL_FAM_TO_STRING:
+    case EVQL_FAM_CONCAT:
+    case EVQL_FAM_LCASE:
+    case EVQL_FAM_UCASE:
+    case EVQL_FAM_SUBSTRING:
+    case EVQL_FAM_LTRIM:
+    case EVQL_FAM_RTRIM:
+      return EVQL_T_STRING;
     case EVQL_FAM_CMP:
     case EVQL_FAM_TO_INT64:
       return EVQL_T_INT64;
@@ -130,7 +146,7 @@ struct Decompiler {
         }
         case EVQL_X_CALL_PURE: {
           int fam = int(op.arg0 / 16), ts = int(op.arg0 % 16);
-          if (fam < EVQL_FAM_LOGICAL_AND || fam > EVQL_FAM_TO_TIMESTAMP64) {
+          if (fam < EVQL_FAM_LOGICAL_AND || fam > EVQL_FAM_LAST) {
             return fail("function not lowerable", true);
           }
           int ar = family_arity(fam);
@@ -496,6 +512,67 @@ std::string eval_expr(const ExprPtr& e, const std::vector<Value>& inputs,
     case EVQL_FAM_TO_TIMESTAMP64:
       if (ts == EVQL_TS_FLOAT64) out->bits = uint64_t(as_f64(a[0].bits));
       else out->bits = a[0].bits;
+      return "";
+    // ---- strings (expressions/string.cc, conversion.cc:140-215) -----------------------
+    case EVQL_FAM_TO_STRING:
+      // sql_tostring (svalue.cc:592-660): a NULL tag reads "NULL"; std::to_string for the
+      // numbers (doubles: "%f"); timestamps go through to_string_uint64_call: decimal
+      if (a[0].tag & EVQL_STAG_NULL) {
+        out->str = "NULL";
+        return "";
+      }
+      switch (ts) {
+        case EVQL_TS_INT64: out->str = std::to_string((long long) int64_t(a[0].bits)); break;
+        case EVQL_TS_FLOAT64: out->str = std::to_string(as_f64(a[0].bits)); break;
+        case EVQL_TS_BOOL: out->str = a[0].bits ? "true" : "false"; break;
+        case EVQL_TS_STRING: out->str = a[0].str; break;
+        case EVQL_TS_NIL: out->str = "NULL"; break;
+        default: out->str = std::to_string((unsigned long long) a[0].bits);
+      }
+      return "";
+    case EVQL_FAM_CONCAT:
+      out->str = a[0].str + a[1].str;
+      return "";
+    case EVQL_FAM_LCASE:
+    case EVQL_FAM_UCASE:
+      out->str = a[0].str;
+      for (char& ch : out->str) {  // std::tolower / toupper in the "C" locale
+        if (fam == EVQL_FAM_LCASE && ch >= 'A' && ch <= 'Z') ch = char(ch - 'A' + 'a');
+        if (fam == EVQL_FAM_UCASE && ch >= 'a' && ch <= 'z') ch = char(ch - 'a' + 'A');
+      }
+      return "";
+    case EVQL_FAM_LTRIM: {
+      size_t i = 0;
+      while (i < a[0].str.size() && a[0].str[i] == ' ') ++i;
+      out->str = a[0].str.substr(i);
+      return "";
+    }
+    case EVQL_FAM_RTRIM: {
+      size_t n = a[0].str.size();
+      while (n > 0 && a[0].str[n - 1] == ' ') --n;
+      out->str = a[0].str.substr(0, n);
+      return "";
+    }
+    case EVQL_FAM_SUBSTRING: {  // string.cc substring_call
+      int64_t cur = int64_t(a[1].bits);
+      const int64_t len = int64_t(a[0].str.size());
+      if (cur == 0 || len == 0) return "";
+      if (cur < 0) {
+        cur += len;
+        if (cur < 0) return "";
+      } else {
+        cur = std::min(cur - 1, len - 1);
+      }
+      out->str = a[0].str.substr(size_t(cur));
+      return "";
+    }
+    case EVQL_FAM_STARTSWITH:
+      out->bits = a[0].str.size() >= a[1].str.size() &&
+                  a[0].str.compare(0, a[1].str.size(), a[1].str) == 0;
+      return "";
+    case EVQL_FAM_ENDSWITH:
+      out->bits = a[0].str.size() >= a[1].str.size() &&
+                  a[0].str.compare(a[0].str.size() - a[1].str.size(), a[1].str.size(), a[1].str) == 0;
       return "";
   }
   return "function not lowerable";

@@ -599,7 +599,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
       if (has_agg_get(lp.call)) return Status::error(EVQL_EARG, "malformed aggregate program");
       ExprPtr e = inline_inputs(lp.call, scan_out, &err);
       if (!err.empty()) return Status::error(EVQL_EARG, err);
-      if (!strings_lowerable(e)) return unsup("string expression is not lowerable");
+      // (no strings_lowerable check: a select expression never reaches the kernel -- it
+      // is evaluated once per group at emission, over the group's first row, like the
+      // reference's method_call run in GroupByExpression::nextBatch; string-producing
+      // functions are fine here)
       if (kp.key_mode == KEY_EXACT && expr_equal(e, kp.group[0])) {
         q->select_passthrough[i] = true;  // value == the group key itself
       } else if (!has_input(e)) {

@@ -3113,6 +3113,11 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
         // SValue::encode (svalue.cc): u8 type, lenenc(value || tag bytes)
         std::vector<uint8_t> enc;
         append_svector(lp.return_type, out, &enc);
+        // A reference quirk kept for byte-identical wire rows: the value is boxed in an
+        // SValue whose 16-byte inline buffer ends in its tag byte, where setData also keeps
+        // the internal STAG_INLINE flag (svalue.cc:346-368).  A value of exactly 16 bytes --
+        // a string of 11 -- therefore leaves with bit 7 set in its tag.
+        if (enc.size() == 16) enc.back() |= 0x80;
         pdata.push_back(uint8_t(lp.return_type));
         put_varuint(&pdata, enc.size());
         pdata.insert(pdata.end(), enc.begin(), enc.end());

@@ -33,6 +33,9 @@ _CMP_FAMS = {"cmp": K.FAM_CMP, "eq": K.FAM_EQ, "neq": K.FAM_NEQ, "lt": K.FAM_LT,
              "lte": K.FAM_LTE, "gt": K.FAM_GT, "gte": K.FAM_GTE}
 _ARITH_FAMS = {"add": K.FAM_ADD, "sub": K.FAM_SUB, "mul": K.FAM_MUL,
                "div": K.FAM_DIV, "mod": K.FAM_MOD, "pow": K.FAM_POW}
+# string -> string functions of expressions/string.cc (lowercase / uppercase are aliases)
+_STR1_FAMS = {"lcase": K.FAM_LCASE, "lowercase": K.FAM_LCASE, "ucase": K.FAM_UCASE,
+              "uppercase": K.FAM_UCASE, "ltrim": K.FAM_LTRIM, "rtrim": K.FAM_RTRIM}
 
 
 class Expr:
@@ -246,6 +249,9 @@ def _resolve_types(e, coltypes):
             if ats != [K.T_BOOL]:
                 raise CompileError("type error for neg")
             e.fn, e.rtype = K.FN(K.FAM_NEG, 0), K.T_BOOL
+        elif n == "add" and ats == [K.T_STRING, K.T_STRING]:
+            # `add` is also registered with expressions::concat (defaults.cc: add -> concat)
+            e.fn, e.rtype = K.FN(K.FAM_CONCAT, K.TS_STRING), K.T_STRING
         elif n in _CMP_FAMS or n in _ARITH_FAMS:
             if len(ats) != 2:
                 raise CompileError("wrong number of arguments for %s" % n)
@@ -278,6 +284,35 @@ def _resolve_types(e, coltypes):
             e.fn, e.rtype = K.FN(K.FAM_TO_NIL, _TS[ats[0]]), K.T_NIL
         elif n == "to_timestamp64":
             e.fn, e.rtype = K.FN(K.FAM_TO_TIMESTAMP64, _TS[ats[0]]), K.T_TIMESTAMP64
+        elif n == "to_string":
+            # conversion.cc:140-215; the timestamp overload shares to_string_uint64's body
+            # and function pointer (the adapter reports it under the uint64 symbol)
+            if len(ats) != 1 or ats[0] == K.T_STRING:
+                raise CompileError("type error for to_string")
+            slot = K.TS_UINT64 if ats[0] == K.T_TIMESTAMP64 else _TS[ats[0]]
+            e.fn, e.rtype = K.FN(K.FAM_TO_STRING, slot), K.T_STRING
+        elif n in ("concat",) or (n == "add" and ats == [K.T_STRING, K.T_STRING]):
+            if ats != [K.T_STRING, K.T_STRING]:
+                raise CompileError("type error for concat")
+            e.fn, e.rtype = K.FN(K.FAM_CONCAT, K.TS_STRING), K.T_STRING
+        elif n in _STR1_FAMS:
+            if ats != [K.T_STRING]:
+                raise CompileError("type error for %s" % n)
+            e.fn, e.rtype = K.FN(_STR1_FAMS[n], K.TS_STRING), K.T_STRING
+        elif n in ("startswith", "endswith"):
+            if ats != [K.T_STRING, K.T_STRING]:
+                raise CompileError("type error for %s" % n)
+            e.fn = K.FN(K.FAM_STARTSWITH if n == "startswith" else K.FAM_ENDSWITH, K.TS_STRING)
+            e.rtype = K.T_BOOL
+        elif n in ("substring", "substr"):
+            if len(ats) != 2 or ats[0] != K.T_STRING or ats[1] not in (K.T_INT64, K.T_UINT64):
+                raise CompileError("type error for substring")
+            if ats[1] == K.T_UINT64:  # implicit UINT64 -> INT64 (CallExpressionNode.cc:58-85)
+                c = Call("to_int64", e.args[1])
+                c.fn = K.FN(K.FAM_TO_INT64, K.TS_UINT64)
+                c.rtype = K.T_INT64
+                e.args[1] = c
+            e.fn, e.rtype = K.FN(K.FAM_SUBSTRING, K.TS_STRING), K.T_STRING
         else:
             raise CompileError("method not found: %s" % n)
         return e

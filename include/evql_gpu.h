@@ -127,8 +127,23 @@ typedef enum {
   EVQL_FAM_POW = 16,
   EVQL_FAM_TO_NIL = 17,   /* conversion.cc:34-93   */
   EVQL_FAM_TO_INT64 = 18, /* conversion.cc:96-137  */
-  EVQL_FAM_TO_TIMESTAMP64 = 19
+  EVQL_FAM_TO_TIMESTAMP64 = 19,
+  /* string functions (expressions/string.cc, conversion.cc:140-215).  They PRODUCE (or
+   * read) strings and are evaluated where the reference evaluates a GROUP BY's select
+   * list: once per group, at emission (groupby.cc:187-220), on the host.  In WHERE,
+   * GROUP BY expressions and aggregate arguments they answer EVQL_ENOTSUP.  Type slot =
+   * the (first) argument's. */
+  EVQL_FAM_TO_STRING = 20,  /* to_string#string/X;  sql_tostring: NULL tag -> "NULL" */
+  EVQL_FAM_CONCAT = 21,     /* concat / add#string/string;string; */
+  EVQL_FAM_LCASE = 22,
+  EVQL_FAM_UCASE = 23,
+  EVQL_FAM_SUBSTRING = 24,  /* substring#string/string;int64; (1-based, negative from the end) */
+  EVQL_FAM_LTRIM = 25,      /* leading / trailing ' ' only */
+  EVQL_FAM_RTRIM = 26,
+  EVQL_FAM_STARTSWITH = 27, /* -> bool */
+  EVQL_FAM_ENDSWITH = 28
 } evql_fn_family;
+#define EVQL_FAM_LAST EVQL_FAM_ENDSWITH
 
 #define EVQL_FN(family, type_slot) ((int64_t)(family) * 16 + (int64_t)(type_slot))
 

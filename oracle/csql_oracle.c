@@ -147,6 +147,16 @@ static void pop_str(vmstack_t* s, const uint8_t** p, uint32_t* len) {
   s->top += 4 + (size_t) *len + 1;
 }
 
+static void push_str(vmstack_t* s, const uint8_t* p, uint32_t len) {
+  /* pushString: u32 len, bytes, tag 0 (one element, pushed in one piece) */
+  uint8_t* b = (uint8_t*) malloc((size_t) len + 5);
+  memcpy(b, &len, 4);
+  if (len) memcpy(b + 4, p, len);
+  b[4 + len] = 0;
+  st_push(s, b, (size_t) len + 5);
+  free(b);
+}
+
 /* ---- aggregate instances --------------------------------------------------- */
 /* count_distinct keeps a std::set<uint64_t> (aggregate.cc:77-80): a hash set
  * here, sorted only when the state is saved */
@@ -440,6 +450,126 @@ static int call_pure(int64_t fn, vmstack_t* s) {
         push_u64(s, v);
       }
       return 0;
+  }
+  /* ---- strings: expressions/string.cc, conversion.cc:140-215 ---------------------------
+   * (popped strings are copied first: a push reuses the stack space they sat in) */
+  switch (fam) {
+    case EVQL_FAM_TO_STRING: { /* sql_tostring, svalue.cc:592-660: NULL tag -> "NULL" */
+      char buf[64];
+      uint8_t tag = 0;
+      switch (ts) {
+        case EVQL_TS_FLOAT64: {
+          double v = pop_f64(s, &tag);
+          /* std::to_string(double) = "%f" */
+          char* big = (char*) malloc(512);
+          int n = snprintf(big, 512, "%f", v);
+          if (tag & EVQL_STAG_NULL) n = snprintf(big, 512, "NULL");
+          push_str(s, (const uint8_t*) big, (uint32_t) n);
+          free(big);
+          return 0;
+        }
+        case EVQL_TS_BOOL: {
+          int v = s->top[0];
+          tag = s->top[1];
+          s->top += 2;
+          snprintf(buf, sizeof(buf), "%s", v ? "true" : "false");
+          break;
+        }
+        case EVQL_TS_STRING: {
+          const uint8_t* p;
+          uint32_t l;
+          pop_str(s, &p, &l); /* (no to_string#string/string; is registered, defaults.cc:110-115) */
+          (void) p;
+          snprintf(g_qerr, sizeof(g_qerr), "to_string(string) is not registered");
+          return -1;
+        }
+        case EVQL_TS_INT64: {
+          int64_t v = (int64_t) pop_u64(s, &tag);
+          snprintf(buf, sizeof(buf), "%lld", (long long) v);
+          break;
+        }
+        case EVQL_TS_NIL:
+          s->top += 1;
+          snprintf(buf, sizeof(buf), "NULL");
+          break;
+        default: { /* uint64, timestamp64 (to_string_uint64_call for both) */
+          uint64_t v = pop_u64(s, &tag);
+          snprintf(buf, sizeof(buf), "%llu", (unsigned long long) v);
+        }
+      }
+      if (tag & EVQL_STAG_NULL) snprintf(buf, sizeof(buf), "NULL");
+      push_str(s, (const uint8_t*) buf, (uint32_t) strlen(buf));
+      return 0;
+    }
+    case EVQL_FAM_CONCAT:
+    case EVQL_FAM_STARTSWITH:
+    case EVQL_FAM_ENDSWITH: {
+      const uint8_t *rp, *lp;
+      uint32_t rl, ll;
+      pop_str(s, &rp, &rl);
+      pop_str(s, &lp, &ll);
+      if (fam == EVQL_FAM_CONCAT) {
+        uint8_t* t = (uint8_t*) malloc((size_t) ll + rl + 1);
+        memcpy(t, lp, ll);
+        memcpy(t + ll, rp, rl);
+        push_str(s, t, ll + rl);
+        free(t);
+      } else if (fam == EVQL_FAM_STARTSWITH) { /* StringUtil::beginsWith */
+        push_bool(s, ll >= rl && memcmp(lp, rp, rl) == 0);
+      } else {
+        push_bool(s, ll >= rl && memcmp(lp + (ll - rl), rp, rl) == 0);
+      }
+      return 0;
+    }
+    case EVQL_FAM_LCASE:
+    case EVQL_FAM_UCASE:
+    case EVQL_FAM_LTRIM:
+    case EVQL_FAM_RTRIM: {
+      const uint8_t* p;
+      uint32_t l;
+      pop_str(s, &p, &l);
+      uint8_t* t = (uint8_t*) malloc((size_t) l + 1);
+      memcpy(t, p, l);
+      uint32_t b = 0, e = l;
+      if (fam == EVQL_FAM_LCASE || fam == EVQL_FAM_UCASE) {
+        for (uint32_t i = 0; i < l; ++i) { /* std::tolower / toupper, "C" locale */
+          if (fam == EVQL_FAM_LCASE && t[i] >= 'A' && t[i] <= 'Z') t[i] = (uint8_t) (t[i] - 'A' + 'a');
+          if (fam == EVQL_FAM_UCASE && t[i] >= 'a' && t[i] <= 'z') t[i] = (uint8_t) (t[i] - 'a' + 'A');
+        }
+      } else if (fam == EVQL_FAM_LTRIM) { /* StringUtil::ltrim: ' ' only */
+        while (b < e && t[b] == ' ') ++b;
+      } else {
+        while (e > b && t[e - 1] == ' ') --e;
+      }
+      push_str(s, t + b, e - b);
+      free(t);
+      return 0;
+    }
+    case EVQL_FAM_SUBSTRING: { /* string.cc substring_call */
+      int64_t cur = (int64_t) pop_u64(s, NULL);
+      const uint8_t* p;
+      uint32_t l;
+      pop_str(s, &p, &l);
+      int64_t len = (int64_t) l;
+      if (cur == 0 || len == 0) {
+        push_str(s, (const uint8_t*) "", 0);
+        return 0;
+      }
+      if (cur < 0) {
+        cur += len;
+        if (cur < 0) {
+          push_str(s, (const uint8_t*) "", 0);
+          return 0;
+        }
+      } else {
+        cur = cur - 1 < len - 1 ? cur - 1 : len - 1;
+      }
+      uint8_t* t = (uint8_t*) malloc((size_t) (len - cur) + 1);
+      memcpy(t, p + cur, (size_t) (len - cur));
+      push_str(s, t, (uint32_t) (len - cur));
+      free(t);
+      return 0;
+    }
   }
   snprintf(g_qerr, sizeof(g_qerr), "unknown function id %lld", (long long) fn);
   return -1;
@@ -1157,11 +1287,15 @@ static orc_result_t* run_chain(orc_table_t* const* tables, int ntables,
             if (p->method_accumulate > 0) {
               agg_save(p->aggregate_fn, &g->inst[e], &data);
             } else {
-              /* SValue::encode: u8 type, lenenc(value|tag bytes) */
+              /* SValue::encode: u8 type, lenenc(value|tag bytes).  The value sat in an
+               * SValue: setData keeps STAG_INLINE in the last byte of the 16-byte inline
+               * buffer (svalue.cc:346-368), which is the value's own tag byte when the
+               * value is exactly 16 bytes long (a string of 11) */
               uint8_t ty = (uint8_t) p->return_type;
               sv_append(&data, &ty, 1);
               sv_varuint(&data, g->boxlen[e]);
               sv_append(&data, g->box[e], g->boxlen[e]);
+              if (g->boxlen[e] == 16) data.data[data.size - 1] |= 0x80;
             }
           }
           uint32_t l = (uint32_t) data.size;

@@ -203,6 +203,24 @@ def survey_cases():
         ("string-predicate", dict(select=[Agg("count", Lit(1)), Agg("sum", a)], group_by=[],
                                   where=Call("logical_and", Call("gte", s, Lit("g5")),
                                              Call("gte", a, Lit(0))))),
+        # string-PRODUCING functions in the select list (expressions/string.cc,
+        # conversion.cc:140-215): evaluated once per group over its first row
+        ("string-functions", dict(
+            select=[k, Call("concat", s, Lit("/x")), Call("add", Lit("k="), Call("to_string", k)),
+                    Call("ucase", s), Call("substring", s, Lit(2)),
+                    Call("substring", s, Lit(9)), Call("startswith", s, Lit("g1")),
+                    Call("endswith", s, Lit("7")), Call("to_string", v), Agg("count", Lit(1))],
+            group_by=[k], where=Call("gt", a, Lit(65000)))),
+        ("string-of-aggregates", dict(
+            select=[k, Call("concat", Lit("n="), Call("to_string", Agg("sum", a))),
+                    Call("to_string", n), Call("ltrim", Call("concat", Lit("  "), s)),
+                    Call("rtrim", Call("concat", s, Lit(" y  "))),
+                    Call("lcase", Call("concat", Lit("MiXeD"), s)),
+                    Call("to_string", Call("gt", a, Lit(40000)))],
+            group_by=[k], where=Call("lt", k, Lit(40)))),
+        ("string-keyed-functions", dict(
+            select=[s, Call("concat", s, s), Call("to_string", Call("add", Agg("count", Lit(1)), Lit(1)))],
+            group_by=[s], where=Call("lt", k, Lit(25)))),
     ]
     out = []
     for cid, kw in cases:

@@ -43,6 +43,8 @@ def render(e):
             return "true" if v else "false"
         if t == K.T_UINT64:
             return "%d" % v
+        if t == K.T_INT64 and v < 0:  # "-5" is an INT64 literal (queryplanbuilder.cc:1519-1529)
+            return "%d" % v
         if t == K.T_FLOAT64:
             if v != v or v in (float("inf"), float("-inf")):
                 raise NotRenderable("non-finite float literal")
@@ -68,6 +70,9 @@ def render(e):
             return "pow(%s, %s)" % (render(e.args[0]), render(e.args[1]))
         if e.name in _INFIX:
             return "(%s %s %s)" % (render(e.args[0]), _INFIX[e.name], render(e.args[1]))
+        if e.name in ("to_string", "concat", "lcase", "ucase", "lowercase", "uppercase", "ltrim",
+                      "rtrim", "substring", "substr", "startswith", "endswith"):
+            return "%s(%s)" % (e.name, ", ".join(render(a) for a in e.args))
         raise NotRenderable("call %s" % e.name)
     raise NotRenderable(repr(e))
 
