@@ -1128,6 +1128,74 @@ __global__ void __launch_bounds__(kBlock) k_lsm_filter(LsmArgs a) {
   }
 }
 
+// ---- nested scans over sibling repeated groups ---------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_record_starts(const u8* levels, const u64* tile_offsets,
+                                                          u64 nslots, u64* starts, u64 max_starts) {
+  const u64 tile = blockIdx.x;
+  const u64 s0 = tile * kDecodeTile + (u64) threadIdx.x * 8;
+  u32 cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt += (s0 + j < nslots && levels[s0 + j] == 0) ? 1u : 0u;
+  u32 total;
+  const u32 ex = block_excl_scan(cnt, &total);
+  u64 k = tile_offsets[tile] + ex;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (s0 + j < nslots && levels[s0 + j] == 0) {
+      if (k < max_starts) starts[k] = s0 + j;  // (zero padding behind the last record)
+      ++k;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_zip_rows(const ZipArgs* ap, u64 nrec, int pass) {
+  const ZipArgs& a = *ap;
+  for (u64 rec = (u64) blockIdx.x * blockDim.x + threadIdx.x; rec < nrec;
+       rec += (u64) gridDim.x * blockDim.x) {
+    u64 cursor[kMaxZipCols], end[kMaxZipCols], cur[kMaxZipCols];
+    for (u32 c = 0; c < a.ncols; ++c) {
+      cursor[c] = a.starts[c] ? a.starts[c][rec] : rec;
+      end[c] = a.starts[c] ? a.starts[c][rec + 1] : rec + 1;
+      cur[c] = EVQL_EMPTY;
+    }
+    u64 row = pass ? a.rows[rec] : 0, nrows = 0;
+    u32 L = 0;
+    // (a record has at least one slot in every column, so the loop emits >= 1 row; the
+    // bound keeps a damaged level stream from spinning)
+    for (u64 guard = 0; guard < (1ull << 32); ++guard) {
+      u32 next_level = 0;
+      for (u32 c = 0; c < a.ncols; ++c) {
+        const bool more = cursor[c] < end[c];
+        const u32 nr = (more && a.levels[c] && cursor[c] != (a.starts[c] ? a.starts[c][rec] : rec))
+                           ? a.levels[c][cursor[c]] : 0u;
+        if (more && nr >= L) cur[c] = cursor[c]++;
+        const u32 nr2 = (cursor[c] < end[c] && a.levels[c]) ? a.levels[c][cursor[c]] : 0u;
+        next_level = nr2 > next_level ? nr2 : next_level;
+      }
+      if (pass) {
+        for (u32 c = 0; c < a.ncols; ++c) a.idx[c][row] = cur[c];
+      }
+      ++row;
+      ++nrows;
+      // cur_select_level_ = cur_fetch_level_; columns at or below it are reset (:511-515)
+      for (u32 c = 0; c < a.ncols; ++c) {
+        if (a.rmax[c] >= next_level) cur[c] = EVQL_EMPTY;
+      }
+      L = next_level;
+      if (L == 0) break;
+    }
+    if (!pass) a.rows[rec] = nrows;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_zip_gather(const u64* vals, const u64* idx, u64 n, u64* out) {
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (u64) gridDim.x * blockDim.x) {
+    const u64 k = idx[i];
+    out[i] = k == EVQL_EMPTY ? 0ull : vals[k];
+  }
+}
+
 // ---- result emission on the device ---------------------------------------------------
 constexpr u8 kStagNull = 1;  // STAG_NULL, sql/svalue.h:52-56
 __device__ __forceinline__ void emit_store9(u8* out, u64 i, u64 bits, u8 tag) {
@@ -2042,6 +2110,29 @@ hipError_t launch_emit_str_sizes(const EmitArgs* d_args, uint32_t c, uint64_t n,
 hipError_t launch_emit_str_bytes(const EmitArgs* d_args, uint32_t c, uint64_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_emit_str_bytes, dim3(grid_for(n)), dim3(kBlock), 0, s, d_args, c, (u64) n);
+  return hipGetLastError();
+}
+
+hipError_t launch_record_starts(const uint8_t* levels, const uint64_t* tile_offsets, uint64_t nslots,
+                                uint64_t* starts, uint64_t max_starts, hipStream_t s) {
+  const u64 ntiles = (nslots + kDecodeTile - 1) / kDecodeTile;
+  if (ntiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_record_starts, dim3((unsigned) ntiles), dim3(kBlock), 0, s, levels,
+                     (const u64*) tile_offsets, (u64) nslots, (u64*) starts, (u64) max_starts);
+  return hipGetLastError();
+}
+
+hipError_t launch_zip_rows(const ZipArgs* d_args, uint64_t nrec, int pass, hipStream_t s) {
+  if (nrec == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_zip_rows, dim3(grid_for(nrec)), dim3(kBlock), 0, s, d_args, (u64) nrec, pass);
+  return hipGetLastError();
+}
+
+hipError_t launch_zip_gather(const uint64_t* vals, const uint64_t* idx, uint64_t n, uint64_t* out,
+                             hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_zip_gather, dim3(grid_for(n)), dim3(kBlock), 0, s, (const u64*) vals,
+                     (const u64*) idx, (u64) n, (u64*) out);
   return hipGetLastError();
 }
 

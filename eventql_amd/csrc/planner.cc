@@ -75,6 +75,55 @@ bool strings_lowerable(const ExprPtr& e, bool root = true) {
   return true;
 }
 
+// A predicate that holds for every row whatever the data: what the reference's planner
+// leaves in place and evaluates per row, e.g. `x >= 0` over an unsigned column (NULL
+// compares as 0, vm.cc:231-272), `(s = '') OR (s != '')`, `(f = true) OR (f = false)`.
+// Operands are columns and literals only (nothing that could raise).  Dropping such a
+// WHERE changes no result; for nested scans it also removes the only way a row could be
+// rejected, and with it the reference's value resets behind rejected rows
+// (CSTableScan.cc:501-515).
+bool simple_operand(const ExprPtr& e) { return e->kind == Expr::INPUT || e->kind == Expr::LITERAL; }
+
+bool expr_always_true(const ExprPtr& e) {
+  if (!e) return false;
+  if (e->kind == Expr::LITERAL) return e->type == EVQL_T_BOOL && e->lit_bits != 0;
+  if (e->kind != Expr::CALL) return false;
+  const auto& a = e->args;
+  switch (e->family) {
+    case EVQL_FAM_LOGICAL_AND:
+      return expr_always_true(a[0]) && expr_always_true(a[1]);
+    case EVQL_FAM_LOGICAL_OR: {
+      if (expr_always_true(a[0]) || expr_always_true(a[1])) return true;
+      if (a[0]->kind != Expr::CALL || a[1]->kind != Expr::CALL) return false;
+      const ExprPtr &l = a[0], &r = a[1];
+      if (l->args.size() != 2 || r->args.size() != 2) return false;
+      if (!simple_operand(l->args[0]) || !simple_operand(l->args[1])) return false;
+      const bool same = expr_equal(l->args[0], r->args[0]) && expr_equal(l->args[1], r->args[1]);
+      // x = y OR x != y  (either order; true for NaN as well: != holds)
+      if (same && ((l->family == EVQL_FAM_EQ && r->family == EVQL_FAM_NEQ) ||
+                   (l->family == EVQL_FAM_NEQ && r->family == EVQL_FAM_EQ))) {
+        return true;
+      }
+      // b = true OR b = false over a BOOL column (values are normalised to 0 / 1)
+      if (l->family == EVQL_FAM_EQ && r->family == EVQL_FAM_EQ && l->type_slot == EVQL_TS_BOOL &&
+          r->type_slot == EVQL_TS_BOOL && expr_equal(l->args[0], r->args[0]) &&
+          l->args[0]->kind == Expr::INPUT && l->args[1]->kind == Expr::LITERAL &&
+          r->args[1]->kind == Expr::LITERAL && (l->args[1]->lit_bits != 0) != (r->args[1]->lit_bits != 0)) {
+        return true;
+      }
+      return false;
+    }
+    case EVQL_FAM_GTE:  // x >= 0, unsigned
+      return (e->type_slot == EVQL_TS_UINT64 || e->type_slot == EVQL_TS_TIMESTAMP64) &&
+             simple_operand(a[0]) && a[1]->kind == Expr::LITERAL && a[1]->lit_bits == 0;
+    case EVQL_FAM_LTE:  // 0 <= x
+      return (e->type_slot == EVQL_TS_UINT64 || e->type_slot == EVQL_TS_TIMESTAMP64) &&
+             simple_operand(a[1]) && a[0]->kind == Expr::LITERAL && a[0]->lit_bits == 0;
+    default:
+      return false;
+  }
+}
+
 // marks the string columns whose bytes the kernel has to reach
 void mark_string_bytes(const ExprPtr& e, std::vector<ColAccess>* cols) {
   if (!e) return;
@@ -364,11 +413,23 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
         if (below && other.rlevel_max < bound) bound = other.rlevel_max;
       }
       if (bound < cl.rlevel_max) {
-        return unsup("nested columns from different repeated groups: " + cl.name + ", " + lc.name);
+        // sibling repeated groups: zipped level by level (runtime.cc materialize_nested_zip);
+        // the record scan's per-record reduction assumes one chain
+        if (within) {
+          return unsup("nested columns from different repeated groups in a record scan: " + cl.name +
+                       ", " + lc.name);
+        }
+        q->nested_siblings = true;
       }
     }
   }
-  if (nested && plan->where) {
+  bool where_always_true = false;
+  if (nested && plan->where && !kp.cols.empty()) {
+    LoweredProgram w;
+    bool wu = false;
+    if (lower_program(*plan->where, &w, &wu).empty()) where_always_true = expr_always_true(w.call);
+  }
+  if (nested && plan->where && !where_always_true) {
     // after a row rejected by WHERE the reference resets parent values without
     // re-reading them (CSTableScan.cc:501-512); only leaf-level-only scans are
     // free of that history dependence
@@ -382,6 +443,9 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
       // reproduced by the runtime (apply_where_resets): a parent value reads 0 behind
       // the first row of its slot when that row was rejected
       if (within) return unsup("WHERE over columns of different repetition depth in a record scan");
+      if (q->nested_siblings) {
+        return unsup("WHERE over columns of different repetition depth from sibling repeated groups");
+      }
       kp.where_rows_kernel = true;
       q->nested_where_mixed = true;
     }
@@ -399,6 +463,10 @@ Status build_kernel_plan(const TableLayout& layout, const evql_plan_desc_t* plan
     if (!strings_lowerable(q->where.call)) return unsup("string expression is not lowerable");
     q->has_where = true;
     kp.where = q->where.call;
+    if (where_always_true) {
+      q->has_where = false;  // holds for every row: no row is rejected, nothing to evaluate
+      kp.where = nullptr;
+    }
     if (nested && kp.cols.empty()) {
       // CSTableScan::fetchNextWithoutColumns (CSTableScan.cc:551-564) skips the
       // record when the predicate is TRUE (`if (popBool(..)) continue;`): a scan

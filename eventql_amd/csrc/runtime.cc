@@ -1069,6 +1069,128 @@ static Status materialize_nested(evql_query* q, const std::vector<ColAccess>& co
   return Status();
 }
 
+// Columns of SIBLING repeated groups (or of groups at different depths that share no
+// chain): CSTableScan::fetchNext zips them level by level (CSTableScan.cc:187-541) -- a row
+// per step of its column automaton; a group that has run out of slots reads the all-zero
+// SValue from then on (:511-515), columns above the fetch level keep their value.  One
+// thread replays that automaton per record (k_zip_rows), first counting the record's rows,
+// then writing the slot every (column, row) reads; the flattened columns are gathered from
+// the per-slot values.  Owned by the operator (not cached on the table).
+static Status materialize_nested_zip(evql_query* q, const std::vector<ColAccess>& cols,
+                                     std::vector<uint64_t*>* flat_out, uint64_t* nrows_out,
+                                     std::vector<uint64_t*>* strpos_out) {
+  evql_table* t = q->table;
+  hipStream_t s = q->ctx->stream;
+  const uint64_t nrec = t->layout.num_rows;
+  const size_t nc = cols.size();
+  if (nc > kMaxZipCols) return Status::error(EVQL_ENOTSUP, "too many columns in a zipped nested scan");
+  flat_out->assign(nc, nullptr);
+  if (strpos_out) strpos_out->assign(nc, nullptr);
+  q->nested_leaf = -1;
+  if (nrec == 0) {
+    *nrows_out = 0;
+    return Status();
+  }
+  ZipArgs za{};
+  za.nrec = nrec;
+  za.ncols = uint32_t(nc);
+  std::vector<DevBuf<uint64_t>> d_vals(nc), d_starts(nc), d_idx(nc);
+  std::vector<DevBuf<uint8_t>> d_levels(nc);
+  std::map<int, size_t> first_use;  // layout index -> first scan column that decoded it
+  for (size_t i = 0; i < nc; ++i) {
+    const int li = cols[i].layout_index;
+    const ColumnLayout& c = t->layout.columns[li];
+    za.rmax[i] = c.rlevel_max;
+    auto seen = first_use.find(li);
+    if (seen != first_use.end()) {
+      const size_t j = seen->second;
+      za.levels[i] = za.levels[j];
+      za.starts[i] = za.starts[j];
+      continue;
+    }
+    first_use[li] = i;
+    uint64_t cap = 0;
+    Status st = nested_slot_values(t, li, nrec, &d_vals[i].p, &cap);
+    if (!st.ok()) return st;
+    if (c.rlevel_max == 0) continue;  // one slot per record: levels / starts stay NULL
+    uint32_t rbits = 0;
+    st = stream_bits(t, c.rlevel_pages, &rbits);
+    if (!st.ok()) return st;
+    if (rbits == 0) return Status::error(EVQL_ENOTSUP, "repeated column without repetition levels");
+    const uint64_t lcap = level_stream_capacity(c.rlevel_pages, rbits);
+    const uint64_t lcapp = padded_rows(lcap);
+    const uint64_t ntiles = (lcap + kDecodeTile - 1) / kDecodeTile;
+    DevBuf<uint64_t> d_cnt;
+    HIP_TRY(d_levels[i].alloc(lcapp));
+    HIP_TRY(hipMemsetAsync(d_levels[i], 0xff, lcapp, s));
+    HIP_TRY(d_cnt.alloc((ntiles + 2) * 8));
+    LevelDecodeArgs la{};
+    la.image = t->d_image;
+    la.pages = t->d_pages[li][1];
+    la.bits = rbits;
+    la.nslots = lcap;
+    la.levels = d_levels[i];
+    for (int k = 0; k < 4; ++k) la.thr[k] = 255;
+    la.counts[0] = d_cnt;
+    la.thr[0] = 0;
+    HIP_TRY(launch_level_decode(la, s));
+    HIP_TRY(launch_exclusive_scan(d_cnt, ntiles, nullptr, s));
+    HIP_TRY(d_starts[i].alloc((nrec + 2) * 8));
+    // (a level stream without zero padding: record `nrec` would start at its end)
+    HIP_TRY(hipMemcpyAsync(d_starts[i].p + nrec, &lcap, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_record_starts(d_levels[i], d_cnt, lcap, d_starts[i], nrec + 1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (cap < lcap && c.dlevel_max > 0) {
+      return Status::error(EVQL_EIO, "level streams of different length: " + c.name);
+    }
+    za.levels[i] = d_levels[i];
+    za.starts[i] = d_starts[i];
+  }
+  DevBuf<uint64_t> d_rows;
+  DevBuf<ZipArgs> d_args;
+  HIP_TRY(d_rows.alloc((nrec + 2) * 8));
+  HIP_TRY(d_args.alloc(sizeof(ZipArgs)));
+  za.rows = d_rows;
+  HIP_TRY(hipMemcpyAsync(d_args, &za, sizeof(ZipArgs), hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_zip_rows(d_args, nrec, 0, s));
+  uint64_t nflat = 0;
+  HIP_TRY(launch_exclusive_scan(d_rows, nrec, d_rows.p + nrec, s));
+  HIP_TRY(hipMemcpyAsync(&nflat, d_rows.p + nrec, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *nrows_out = nflat;
+  const uint64_t flatp = padded_rows(nflat);
+  for (size_t i = 0; i < nc; ++i) {
+    HIP_TRY(d_idx[i].alloc(std::max<uint64_t>(nflat, 1) * 8));
+    za.idx[i] = d_idx[i];
+  }
+  HIP_TRY(hipMemcpyAsync(d_args, &za, sizeof(ZipArgs), hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_zip_rows(d_args, nrec, 1, s));
+  for (size_t i = 0; i < nc; ++i) {
+    const int li = cols[i].layout_index;
+    const size_t src = first_use[li];
+    DevBuf<uint64_t> d_flat;
+    HIP_TRY(d_flat.alloc(flatp * 8));
+    HIP_TRY(hipMemsetAsync(d_flat, 0, flatp * 8, s));
+    HIP_TRY(launch_zip_gather(d_vals[src], d_idx[i], nflat, d_flat, s));
+    if (cols[i].string_hash) {
+      // the flattened words are (len << 40 | position); a reset slot reads strpos 0: ""
+      DevBuf<uint64_t> d_hash;
+      HIP_TRY(d_hash.alloc(flatp * 8));
+      HIP_TRY(hipMemsetAsync(d_hash, 0, flatp * 8, s));
+      HIP_TRY(launch_string_hash(t->d_image, t->d_pages[li][0], d_flat, nflat, d_hash, s));
+      (*flat_out)[i] = d_hash;
+      if (strpos_out) (*strpos_out)[i] = d_flat;
+      q->nested_owned.push_back(d_hash.release());
+      q->nested_owned.push_back(d_flat.release());
+    } else {
+      (*flat_out)[i] = d_flat;
+      q->nested_owned.push_back(d_flat.release());
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return Status();
+}
+
 // CSTableScan with AGGREGATE_WITHIN_RECORD_FLAT (CSTableScan.cc:440-487): one
 // output row per record holding the scan select list's aggregates over the
 // record's flattened rows.  select_list_[i] accumulates on the rows whose fetch
@@ -1342,10 +1464,23 @@ Status query_prepare(evql_query* q) {
     Status st = materialize_within_record(q);
     if (!st.ok()) return st;
   } else if (q->nested) {
-    Status st = materialize_nested(q, q->kp.cols, &q->nested_flat, &q->nested_rows,
-                                   q->nested_where_mixed ? &where_leaf : nullptr,
-                                   &q->nested_strpos);
-    if (!st.ok()) return st;
+    Status st;
+    if (!q->nested_siblings) {
+      st = materialize_nested(q, q->kp.cols, &q->nested_flat, &q->nested_rows,
+                              q->nested_where_mixed ? &where_leaf : nullptr, &q->nested_strpos);
+      // (the planner's chain check reads names only: groups that merely look like one
+      // chain are caught by the slot counts)
+      if (!st.ok() && st.code == EVQL_ENOTSUP && !q->nested_where_mixed &&
+          st.msg.find("different repeated groups") != std::string::npos) {
+        q->nested_siblings = true;
+      } else if (!st.ok()) {
+        return st;
+      }
+    }
+    if (q->nested_siblings) {
+      st = materialize_nested_zip(q, q->kp.cols, &q->nested_flat, &q->nested_rows, &q->nested_strpos);
+      if (!st.ok()) return st;
+    }
   }
   // resolve bit widths and materialise SoA columns
   bool repacked = false;

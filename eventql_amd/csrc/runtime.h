@@ -292,6 +292,7 @@ struct evql_query {
   int nested_leaf = -1;  // layout index of the leaf column of the scan
   std::vector<uint64_t*> nested_owned;
   bool nested_where_mixed = false;  // WHERE over columns of different repetition depth
+  bool nested_siblings = false;     // columns of sibling repeated groups: zipped (materialize_nested_zip)
   // EVQL_SCAN_NESTED_WITHIN_RECORD (CSTableScan.cc:440-487,
   // AGGREGATE_WITHIN_RECORD_FLAT): the scan select list holds one aggregate per
   // expression, reduced to one value per record; those per-record arrays are

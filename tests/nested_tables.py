@@ -33,6 +33,19 @@ NESTED_SCHEMA = {
 }
 
 
+# columns of testtbl.cst from SIBLING repeated groups (event.cart_items / event.page_view /
+# event.search_query are repeated side by side, result_items sits below search_query):
+# CSTableScan zips them level by level (CSTableScan.cc:187-541)
+SIBLING_SCHEMA = dict(NESTED_SCHEMA, **{
+    "event.cart_items.quantity": K.T_UINT64,
+    "event.cart_items.price_cents": K.T_UINT64,
+    "event.cart_items.item_id": K.T_STRING,
+    "event.page_view.time": K.T_UINT64,
+    "event.page_view.item_id": K.T_STRING,
+    "event.search_query.page": K.T_UINT64,
+})
+
+
 @functools.lru_cache(maxsize=1)
 def testtbl_v2():
     """the reference's v0.1.0 fixture re-encoded as cstable v0.2.0: identical

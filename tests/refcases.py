@@ -111,7 +111,7 @@ def table_image(key):
         return N.items_table(50_000)[0], N.ITEMS_SCHEMA, "dremel"
     if key == "testtbl":
         # the reference's own checked-in fixture, read as the v0.1.0 file it is
-        return open(T.GOLDEN + "/testtbl.cst", "rb").read(), N.NESTED_SCHEMA, "dremel"
+        return open(T.GOLDEN + "/testtbl.cst", "rb").read(), N.SIBLING_SCHEMA, "dremel"
     raise KeyError(key)
 
 
@@ -317,6 +317,61 @@ def lsm_cases():
     return out
 
 
+@suite("siblings")
+def sibling_cases():
+    """CSTableScan over columns of SIBLING repeated groups of testtbl.cst (cart_items,
+    page_view, search_query side by side; result_items below search_query): zipped level by
+    level, a group that has run out of slots reads the all-zero SValue"""
+    import nested_tables as N
+    S = N.SIBLING_SCHEMA
+    cq, cp, ci = _c("event.cart_items.quantity"), _c("event.cart_items.price_cents"), _c("event.cart_items.item_id")
+    pt, pi = _c("event.page_view.time"), _c("event.page_view.item_id")
+    st, sp, sn = _c("event.search_query.time"), _c("event.search_query.page"), _c("event.search_query.num_result_items")
+    rp, rc = _c("event.search_query.result_items.position"), _c("event.search_query.result_items.clicked")
+    tm, sid = _c("time"), _c("session_id")
+    one = Agg("count", Lit(1))
+    named = [
+        ("two-groups", dict(select=[cq, one, Agg("sum", pt)], group_by=[cq])),
+        ("three-groups", dict(select=[sp, one, Agg("sum", cq), Agg("sum", pt)], group_by=[sp])),
+        ("with-flat", dict(select=[cq, one, Agg("sum", tm), Agg("sum", pt)], group_by=[cq])),
+        ("depth-1-and-2", dict(select=[rp, one, Agg("sum", cq)], group_by=[rp])),
+        ("depth-2-and-two-siblings", dict(select=[cq, one, Agg("sum", rp), Agg("sum", pt), Agg("sum", sn)],
+                                          group_by=[cq])),
+        ("string-keys", dict(select=[ci, one, Agg("sum", pt)], group_by=[ci])),
+        ("string-first-rows", dict(select=[cq, pi, ci, sid, one], group_by=[cq])),
+        ("two-key-columns", dict(select=[cq, sp, one, Agg("sum", cp)], group_by=[cq, sp])),
+        ("bool-leaf", dict(select=[rc, one, Agg("sum", cq), Agg("count_distinct", pt)], group_by=[rc])),
+        ("global", dict(select=[one, Agg("sum", cq), Agg("sum", pt), Agg("sum", rp)], group_by=[])),
+        # a real predicate over columns of ONE depth (both groups at depth 1)
+        ("where-depth-1", dict(select=[cq, one, Agg("sum", pt)], group_by=[cq],
+                               where=Call("logical_or", Call("gt", cq, Lit(1)), Call("gt", pt, Lit(0))))),
+    ]
+    out = []
+    for cid, kw in named:
+        c = _case("siblings-" + cid, "testtbl", kw, S, scan_mode=K.SCAN_NESTED)
+        assert c is not None, cid
+        out.append(c)
+    d1 = ["event.cart_items.quantity", "event.cart_items.price_cents", "event.page_view.time",
+          "event.search_query.page", "event.search_query.num_result_items", "event.search_query.time"]
+    for seed in range(40):
+        r = random.Random(90_000 + seed)
+        cols = r.sample(d1, r.choice([2, 3, 4]))
+        if r.random() < 0.4:
+            cols.append("event.search_query.result_items.position")
+        if r.random() < 0.4:
+            cols.append("time")
+        r.shuffle(cols)
+        key = _c(cols[0])
+        sel = [key, one] + [Agg(r.choice(["sum", "sum", "count", "count_distinct"]), _c(x)) for x in cols[1:]]
+        if r.random() < 0.3:
+            sel.insert(1, _c(cols[1]))  # a first-row value
+        c = _case("siblings-r%02d" % seed, "testtbl", dict(select=sel, group_by=[key]), S,
+                  scan_mode=K.SCAN_NESTED)
+        if c:
+            out.append(c)
+    return out
+
+
 def all_cases():
     return {name: fn() for name, fn in SUITES.items()}
 
@@ -327,4 +382,4 @@ def table_schema(key):
         import lsm_tables
         return lsm_tables.LSM_SCHEMA
     return {"mixed": T.MIXED_SCHEMA, "ranges": T.RANGES_SCHEMA, "survey": T.SURVEY_SCHEMA,
-            "items": N.ITEMS_SCHEMA, "testtbl": N.NESTED_SCHEMA}[key]
+            "items": N.ITEMS_SCHEMA, "testtbl": N.SIBLING_SCHEMA}[key]

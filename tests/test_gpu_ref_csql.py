@@ -171,7 +171,9 @@ def test_reference_engine_with_gpu_operator(suite):
                 assert rows[:len(want["rows"])] == want["rows"], c["id"]
                 assert sqlgen.rows_digest(rows) == want["digest"], c["id"]
     # the GPU operator, not the CPU fallback, produced (most of) these
-    assert lowered >= (0.9 if suite != "nested" else 0.3) * len(cases), (lowered, len(cases))
+    # (nested plans: every one of them lowers since the mixed-depth WHERE resets, strings at
+    # every depth and sibling repeated groups are; the soak of round 2 measured 100 %)
+    assert lowered >= 0.9 * len(cases), (lowered, len(cases))
 
 
 @pytest.mark.skipif(not os.path.exists(PROBE), reason="oracle/_ref/csql_probe not built "
