@@ -37,6 +37,8 @@
  *   TIME <n> <statement>                    run it n times, report best seconds
  *   WRITE <file.cst> <nrows> <seed>         SURVEY 8c(ii) xorshift table through
  *                                           the reference's own CSTableWriter
+ *   BUDGET <bytes>                          a fresh GPU table registry with this HBM budget
+ *                                           (registered tables are forgotten)
  *   PARTITION <name> <dir> <file>:<skiplist>:<updates> ...
  *                                           a table whose scans are the reference's own
  *                                           eventql::PartitionCursor (server/sql/
@@ -489,6 +491,7 @@ struct Probe {
       }
       o << "]";
       o << ",\"query_cache_hits\":" << scheduler->probeCacheHits();
+      o << ",\"resident_bytes\":" << registry->residentBytes();
     }
     return o.str();
   }
@@ -595,6 +598,12 @@ int main(int argc, char** argv) {
             }
             return RefPtr<eventql::PartitionSnapshot>();
           }));
+    } else if (cmd == "BUDGET") {
+      unsigned long long bytes = 0;
+      is >> bytes;
+      probe.registry = std::make_shared<GpuTableRegistry>(0, (uint64_t) bytes);
+      probe.tables.clear();
+      probe.installScheduler();
     } else if (cmd == "CACHE") {
       std::string dir;
       is >> dir;

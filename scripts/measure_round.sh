@@ -3,7 +3,7 @@
 # summaries are committed under profiles/.  usage: scripts/measure_round.sh <tag> <part>
 #   part 1: bench lines of every workload;  part 2: kernel traces + PMC passes
 set -eo pipefail
-TAG=${1:-r02}; PART=${2:-1}
+TAG=${1:-r03}; PART=${2:-1}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -263,3 +263,65 @@ def test_evqld_scheduler_mixin(suite):
     node half of a distributed GROUP BY: PartialGroupByExpression's GPU twin for the plans
     it lowers, eventql::Scheduler's CPU operator for the rest, identical bytes"""
     run_evqld_mode(suite, 0.85)
+
+
+@pytest.mark.skipif(not os.path.exists(PROBE), reason="oracle/_ref/csql_probe not built "
+                    "(needs /root/reference at build time)")
+def test_registry_follows_the_file_and_keeps_to_its_budget():
+    """GpuTableRegistry (adapter): a table name stays bound to its file; when the file
+    behind the name changes (size / mtime) the resident copy is dropped and the new
+    contents are read; resident bytes stay under the registry's budget (least recently
+    used files leave first)"""
+    import numpy as np
+    from eventql_amd import synth
+
+    def table(n, seed):
+        c = synth.table_columns(n, seed=seed)
+        w = E.Writer([dict(name=x, logical_type=K.COL_UNSIGNED_INT, storage_type=K.ENC_UINT64_PLAIN)
+                      for x in "kab"])
+        for x in "kab":
+            w.put(x, c[x])
+        w.commit(n)
+        img = w.image()
+        w.close()
+        return img, c
+    q = "select count(1), sum(a) from t where a >= 0;"
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = [os.path.join(tmp, "t%d.cst" % i) for i in range(3)]
+        sizes = []
+        for i, p in enumerate(paths):
+            img, _ = table(100_000 + 50_000 * i, 7 + i)
+            sizes.append(len(img))
+            with open(p, "wb") as f:
+                f.write(img)
+        budget = sizes[0] + sizes[1] + 1000   # room for two of the three files
+        img2, c2 = table(60_000, 99)
+        cmds = ["BUDGET %d" % budget, "ROWS on", "MODE gpu strict",
+                "TABLE t %s fast" % paths[0], "SQL " + q,
+                "TABLE t %s fast" % paths[1], "SQL " + q,
+                "TABLE t %s fast" % paths[2], "SQL " + q]
+        p = subprocess.run([PROBE], input="\n".join(cmds) + "\n", capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res = [json.loads(l) for l in p.stdout.splitlines() if l.strip()]
+        assert all(r["ok"] for r in res), [r.get("error") for r in res]
+        assert [r["rows"][0][0] for r in res] == [100_000, 150_000, 200_000]
+        assert all(r["resident_bytes"] <= budget for r in res), [r["resident_bytes"] for r in res]
+        # the file behind a name changes while the process keeps running: one probe process,
+        # the second statement is sent after the file was rewritten
+        pr = subprocess.Popen([PROBE], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        pr.stdin.write("\n".join(["ROWS on", "MODE gpu strict", "TABLE t %s fast" % paths[0], "SQL " + q]) + "\n")
+        pr.stdin.flush()
+        first = json.loads(pr.stdout.readline())
+        assert first["ok"] and first["rows"][0][0] == 100_000
+        import time
+        time.sleep(0.05)
+        with open(paths[0], "wb") as f:
+            f.write(img2)
+        pr.stdin.write("SQL " + q + "\n")
+        pr.stdin.flush()
+        second = json.loads(pr.stdout.readline())
+        pr.stdin.close()
+        pr.wait(timeout=60)
+        assert second["ok"], second.get("error")
+        assert second["rows"][0] == [60_000, int(c2["a"].astype(np.uint64).sum())]
