@@ -94,30 +94,107 @@ __device__ __forceinline__ void rt_atomic(u32 op, u64* p, u64 v) {
   }
 }
 
+// the same combine without the atomic: for slots with one writer per launch (MergeArgs::exclusive)
+__device__ __forceinline__ void rt_plain(u32 op, u64* p, u64 v) {
+  const u64 o = *p;
+  u64 r;
+  switch (op) {
+    case EVQL_OP_ADD_U64: r = o + v; break;
+    case EVQL_OP_ADD_F64: r = evql_f64_bits(evql_as_f64(o) + evql_as_f64(v)); break;
+    case EVQL_OP_MIN_U64: r = v < o ? v : o; break;
+    case EVQL_OP_MAX_U64: r = v > o ? v : o; break;
+    case EVQL_OP_MIN_I64: r = (i64) v < (i64) o ? v : o; break;
+    case EVQL_OP_MAX_I64: r = (i64) v > (i64) o ? v : o; break;
+    case EVQL_OP_MIN_F64: r = evql_as_f64(v) < evql_as_f64(o) ? v : o; break;
+    case EVQL_OP_MAX_F64: r = evql_as_f64(v) > evql_as_f64(o) ? v : o; break;
+    default: return;
+  }
+  *p = r;
+}
+
+// slot of a record's group in an HBM table (claimed when new); *fresh = this call claimed it
+__device__ __forceinline__ i64 merge_slot(const MergeArgs& a, const u64* rec, bool* fresh) {
+  u64* words = (u64*) a.words;
+  const u64 kind = rec[0], ident = rec[1];
+  *fresh = false;
+  if (kind == 1 || kind == 2) {
+    // the group of the empty key / the NULL key: at most one record per launch
+    const u64 gs = a.gcap + (kind - 1);
+    u64* key = words + gs * a.nwords;
+    if (a.exclusive) *fresh = __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == EVQL_EMPTY;
+    *key = 0;
+    return (i64) gs;
+  }
+  if (!a.exclusive) {
+    return a.has_ident2 ? evql_gtab_find2(words, a.nwords, a.gcap, ident, rec[2], evql_mix64(ident))
+                        : evql_gtab_find(words, a.nwords, a.gcap, ident, evql_mix64(ident));
+  }
+  // (the probe loops of evql_gtab_find / _find2, also telling who claimed the slot)
+  const u64 mask = a.gcap - 1;
+  u64 s = evql_mix64(ident) & mask;
+  const u64 maxp = a.gcap < EVQL_GTAB_MAX_PROBE ? a.gcap : EVQL_GTAB_MAX_PROBE;
+#pragma unroll 1
+  for (u64 probe = 0; probe < maxp; ++probe) {
+    u64* key = words + s * a.nwords;
+    u64 cur = __hip_atomic_load(key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool claimed = false;
+    if (cur == EVQL_EMPTY) {
+      cur = atomicCAS(key, EVQL_EMPTY, ident);
+      claimed = cur == EVQL_EMPTY;
+    }
+    if (claimed || cur == ident) {
+      if (!a.has_ident2) {
+        *fresh = claimed;
+        return (i64) s;
+      }
+      u64 c2 = __hip_atomic_load(key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool claimed2 = false;
+      if (c2 == EVQL_EMPTY) {
+        c2 = atomicCAS(key + 1, EVQL_EMPTY, rec[2]);
+        claimed2 = c2 == EVQL_EMPTY;
+      }
+      if (claimed2 || c2 == rec[2]) {
+        *fresh = claimed2;
+        return (i64) s;
+      }
+    }
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+// one atomic per wave for the slots its lanes claimed
+__device__ __forceinline__ void merge_count_fresh(const MergeArgs& a, bool fresh) {
+  if (!a.exclusive || !a.fresh) return;
+  const u64 m = __ballot(fresh);
+  if (m && (threadIdx.x & 63) == (u32) (__ffsll((long long) m) - 1)) {
+    atomicAdd((unsigned long long*) a.fresh, (unsigned long long) __popcll(m));
+  }
+}
+
 __global__ void k_table_merge(MergeArgs a, const u64* records, u64 n) {
-  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (u64) gridDim.x * blockDim.x) {
-    const u64* rec = records + i * (a.nwords + 1);
-    const u64 kind = rec[0], ident = rec[1];
-    i64 gs;
-    if (kind == 1) {
-      gs = (i64) a.gcap;
-      a.words[(u64) gs * a.nwords] = 0;
-    } else if (kind == 2) {
-      gs = (i64) a.gcap + 1;
-      a.words[(u64) gs * a.nwords] = 0;
-    } else {
-      gs = a.has_ident2
-               ? evql_gtab_find2((u64*) a.words, a.nwords, a.gcap, ident, rec[2], evql_mix64(ident))
-               : evql_gtab_find((u64*) a.words, a.nwords, a.gcap, ident, evql_mix64(ident));
+  const u64 step = (u64) gridDim.x * blockDim.x;
+  const u64 rounds = (n + step - 1) / step;
+  for (u64 it = 0; it < rounds; ++it) {
+    const u64 i = it * step + (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    bool fresh = false;
+    if (i < n) {
+      const u64* rec = records + i * (a.nwords + 1);
+      const i64 gs = merge_slot(a, rec, &fresh);
+      if (gs < 0) {
+        atomicOr(&a.status[0], EVQL_ST_TABLE_FULL);
+      } else {
+        u64* slot = (u64*) a.words + (u64) gs * a.nwords;
+        for (u32 w = 1 + a.has_ident2; w < a.nwords; ++w) {
+          if (a.exclusive) {
+            rt_plain(a.ops[w], &slot[w], rec[1 + w]);
+          } else {
+            rt_atomic(a.ops[w], &slot[w], rec[1 + w]);
+          }
+        }
+      }
     }
-    if (gs < 0) {
-      atomicOr(&a.status[0], EVQL_ST_TABLE_FULL);
-      continue;
-    }
-    for (u32 w = 1 + a.has_ident2; w < a.nwords; ++w) {
-      rt_atomic(a.ops[w], (u64*) &a.words[(u64) gs * a.nwords + w], rec[1 + w]);
-    }
+    merge_count_fresh(a, fresh);
   }
 }
 
@@ -355,47 +432,49 @@ __global__ void __launch_bounds__(kBlock) k_wire_str_copy(WireStrArgs a) {
 __global__ void __launch_bounds__(kBlock) k_table_merge_resolved(MergeResolvedArgs a,
                                                                  const u64* records, u64 n) {
   const u32 rw = a.m.nwords + 1;
-  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (u64) gridDim.x * blockDim.x) {
-    const u64* rec = records + i * rw;
-    const u64 kind = rec[0], ident = rec[1];
-    u64* words = (u64*) a.m.words;
-    i64 gs;
-    if (kind == 1) {
-      gs = (i64) a.m.gcap;
-      words[(u64) gs * a.m.nwords] = 0;
-    } else if (kind == 2) {
-      gs = (i64) a.m.gcap + 1;
-      words[(u64) gs * a.m.nwords] = 0;
-    } else {
-      gs = a.m.has_ident2 ? evql_gtab_find2(words, a.m.nwords, a.m.gcap, ident, rec[2], evql_mix64(ident))
-                          : evql_gtab_find(words, a.m.nwords, a.m.gcap, ident, evql_mix64(ident));
-    }
-    if (gs < 0) {
-      atomicOr(&a.m.status[0], EVQL_ST_TABLE_FULL);
-      continue;
-    }
-    u64* slot = words + (u64) gs * a.m.nwords;
-    bool first = false;
-    for (u32 w = 1 + a.m.has_ident2; w < a.state_words; ++w) {
-      if (w == a.first_row_word) {
-        const u64 old = atomicMin((unsigned long long*) &slot[w], (unsigned long long) rec[1 + w]);
-        first = old == EVQL_EMPTY;
+  const u64 step = (u64) gridDim.x * blockDim.x;
+  const u64 rounds = (n + step - 1) / step;
+  for (u64 it = 0; it < rounds; ++it) {
+    const u64 i = it * step + (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    bool fresh = false;
+    if (i < n) {
+      const u64* rec = records + i * rw;
+      const i64 gs = merge_slot(a.m, rec, &fresh);
+      if (gs < 0) {
+        atomicOr(&a.m.status[0], EVQL_ST_TABLE_FULL);
       } else {
-        rt_atomic(a.m.ops[w], &slot[w], rec[1 + w]);
-      }
-    }
-    if (first) {
-      // (one record per group and batch, batches merged one after the other: the
-      // first entry of a group has exactly one writer)
-      for (u32 c = 0; c <= a.ncols; ++c) {
-        u64 v = rec[1 + a.state_words + c];
-        if (c < a.ncols && ((a.str_mask >> c) & 1)) {
-          v = (v & ~kStrOffMask) | (((v & kStrOffMask) + a.heap_base) & kStrOffMask);
+        u64* slot = (u64*) a.m.words + (u64) gs * a.m.nwords;
+        bool first = false;
+        for (u32 w = 1 + a.m.has_ident2; w < a.state_words; ++w) {
+          if (w == a.first_row_word) {
+            if (a.m.exclusive) {
+              const u64 old = slot[w];
+              first = old == EVQL_EMPTY;
+              if (rec[1 + w] < old) slot[w] = rec[1 + w];
+            } else {
+              const u64 old = atomicMin((unsigned long long*) &slot[w], (unsigned long long) rec[1 + w]);
+              first = old == EVQL_EMPTY;
+            }
+          } else if (a.m.exclusive) {
+            rt_plain(a.m.ops[w], &slot[w], rec[1 + w]);
+          } else {
+            rt_atomic(a.m.ops[w], &slot[w], rec[1 + w]);
+          }
         }
-        slot[a.state_words + c] = v;
+        if (first) {
+          // (one record per group and batch, batches merged one after the other: the
+          // first entry of a group has exactly one writer)
+          for (u32 c = 0; c <= a.ncols; ++c) {
+            u64 v = rec[1 + a.state_words + c];
+            if (c < a.ncols && ((a.str_mask >> c) & 1)) {
+              v = (v & ~kStrOffMask) | (((v & kStrOffMask) + a.heap_base) & kStrOffMask);
+            }
+            slot[a.state_words + c] = v;
+          }
+        }
       }
     }
+    merge_count_fresh(a.m, fresh);
   }
 }
 

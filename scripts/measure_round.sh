@@ -44,6 +44,10 @@ else
   kt config4 --steps 5 --warmup 1 --workload config4
   kt config4s --steps 5 --warmup 1 --workload config4s
   kt config3l --steps 10 --warmup 2 --workload config3l
+  kt config4_nohint --steps 5 --warmup 1 --workload config4 --no-hint
+  kt config5 --steps 10 --warmup 2 --workload config5
+  kt config5w --steps 5 --warmup 1 --workload config5w
+  kt config2 --steps 10 --warmup 2 --workload config2
   for c in FETCH_SIZE WRITE_SIZE; do
     pmc $c config3 --steps 3 --warmup 1
     pmc $c config4 --steps 3 --warmup 1 --workload config4
