@@ -179,7 +179,8 @@ HEARTBEAT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 class ExchangeStats(C.Structure):
     _fields_ = [("groups_sent", C.c_uint64), ("groups_received", C.c_uint64),
                 ("bytes_sent", C.c_uint64), ("export_ms", C.c_double),
-                ("transfer_ms", C.c_double), ("merge_ms", C.c_double)]
+                ("transfer_ms", C.c_double), ("merge_ms", C.c_double),
+                ("merge_buckets", C.c_uint64)]
 
 
 EXCHANGE_GATHER_ALL = 0

@@ -478,6 +478,210 @@ __global__ void __launch_bounds__(kBlock) k_table_merge_resolved(MergeResolvedAr
   }
 }
 
+// ---- bucketed merge (aot_kernels.h BucketScatterArgs / BucketMergeArgs) ------------------
+constexpr u64 kBucketSalt = 0x6a09e667f3bcc909ull;
+constexpr u32 kBucketTileMax = 2048;
+
+__device__ __forceinline__ u32 bucket_bin(const u64* rec, u32 shift, u32 bins) {
+  // (the groups of the empty / the NULL key carry no identity to hash: bucket 0)
+  return rec[0] != 0 ? 0u : (u32) (evql_mix64(rec[1] ^ kBucketSalt) >> shift) & (bins - 1);
+}
+
+// One pass of the split: every tile of an input region is sorted by bin in the LDS
+// (histogram, ranks and the staged records), one cursor add per bin and tile reserves the
+// run in the bin's output region, and the runs leave as whole lines.
+__global__ void __launch_bounds__(kBlock) k_bucket_scatter(BucketScatterArgs a) {
+  extern __shared__ u64 staged[];  // tile x rw words
+  __shared__ u32 hist[256], loff[256];
+  __shared__ u64 gbase[256];
+  __shared__ u8 sbin[kBucketTileMax];
+  const u32 tid = threadIdx.x;
+  const u64 vtiles = (u64) a.in_regions * a.tiles_per_region;
+  for (u64 vt = blockIdx.x; vt < vtiles; vt += gridDim.x) {
+    const u32 reg = (u32) (vt / a.tiles_per_region);
+    const u64 t0 = (vt % a.tiles_per_region) * a.tile;
+    u64 cnt = a.n_in;
+    if (a.in_counts) {
+      cnt = a.in_counts[reg];
+      if (cnt > a.in_region_cap) cnt = a.in_region_cap;
+    }
+    if (t0 >= cnt) continue;  // (uniform)
+    const u32 nvalid = cnt - t0 < a.tile ? (u32) (cnt - t0) : a.tile;
+    const u64* src = (const u64*) a.in + ((u64) reg * a.in_region_cap + t0) * a.rw;
+    hist[tid] = 0;
+    __syncthreads();
+    u32 mybin[kBucketTileMax / kBlock], myrank[kBucketTileMax / kBlock];
+#pragma unroll
+    for (u32 j = 0; j < kBucketTileMax / kBlock; ++j) {
+      const u32 p = j * kBlock + tid;
+      mybin[j] = 0;
+      myrank[j] = 0;
+      if (p < nvalid && p < a.tile) {
+        mybin[j] = bucket_bin(src + (u64) p * a.rw, a.shift, a.bins);
+        myrank[j] = atomicAdd(&hist[mybin[j]], 1u);
+      }
+    }
+    __syncthreads();
+    const u32 c = hist[tid];
+    u32 total;
+    const u32 ex = block_excl_scan(c, &total);
+    loff[tid] = ex;
+    gbase[tid] = ~0ull;
+    if (c) {
+      const u64 outreg = (u64) reg * a.bins + tid;
+      const u64 g = atomicAdd((unsigned long long*) &a.out_counts[outreg], (unsigned long long) c);
+      if (g + c > a.out_region_cap) {
+        atomicOr(a.status, 1u);
+      } else {
+        gbase[tid] = (outreg * a.out_region_cap + g) * a.rw;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < kBucketTileMax / kBlock; ++j) {
+      const u32 p = j * kBlock + tid;
+      if (p < nvalid && p < a.tile) {
+        const u64* rec = src + (u64) p * a.rw;
+        const u32 dst = loff[mybin[j]] + myrank[j];
+        sbin[dst] = (u8) mybin[j];
+        u64* d = staged + (u64) dst * a.rw;
+        for (u32 w = 0; w < a.rw; ++w) d[w] = rec[w];
+        if (a.nranks && a.str_mask) {
+          // string words are (len << 40 | offset into the sender's bytes): the bytes of
+          // rank r lie at heap_base[r] of the received heap
+          const u64 i = t0 + p;
+          u32 r = 0;
+          while (r + 1 < a.nranks && i >= a.rank_start[r + 1]) ++r;
+          const u64 hb = a.heap_base[r];
+          for (u32 col = 0; col < a.ncols; ++col) {
+            if (!((a.str_mask >> col) & 1)) continue;
+            const u64 v = d[a.first_value_word + col];
+            d[a.first_value_word + col] = (v & ~kStrOffMask) | (((v & kStrOffMask) + hb) & kStrOffMask);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const u32 nwords = nvalid * a.rw;
+    for (u32 idx = tid; idx < nwords; idx += kBlock) {
+      const u32 p = (u32) (((u64) idx * a.rw_inv) >> 32);
+      const u32 w = idx - p * a.rw;
+      const u32 b = sbin[p];
+      const u64 gb = gbase[b];
+      if (gb != ~0ull) a.out[gb + (u64) (p - loff[b]) * a.rw + w] = staged[idx];
+    }
+    __syncthreads();
+  }
+}
+
+// slot of a record's group in the LDS table of its bucket; `claim`: insert when new
+__device__ __forceinline__ int bucket_find(u64* tab, const BucketMergeArgs& a, const u64* rec,
+                                           bool claim) {
+  const u64 kind = rec[0];
+  if (kind != 0) {
+    u64* key = tab + (u64) (a.lds_slots + (u32) kind - 1) * a.mw;
+    if (claim) {
+      *key = 0;
+    } else if (evql_lds_peek(key) == EVQL_EMPTY) {
+      return -1;
+    }
+    return (int) (a.lds_slots + (u32) kind - 1);
+  }
+  const u64 ident = rec[1];
+  const u32 mask = a.lds_slots - 1;
+  u32 s = (u32) evql_mix64(ident ^ kBucketSalt) & mask;
+#pragma unroll 1
+  for (u32 probe = 0; probe < a.lds_slots; ++probe) {
+    u64* key = tab + (u64) s * a.mw;
+    u64 cur = evql_lds_peek(key);
+    if (cur == EVQL_EMPTY) {
+      if (!claim) return -1;
+      cur = atomicCAS((unsigned long long*) key, (unsigned long long) EVQL_EMPTY, (unsigned long long) ident);
+      if (cur == EVQL_EMPTY) cur = ident;
+    }
+    if (cur == ident) {
+      if (!a.has_ident2) return (int) s;
+      // (the protocol of evql_gtab_find2: two keys that agree in the first word race for
+      // the second one, the loser moves on along the chain)
+      u64 c2 = evql_lds_peek(key + 1);
+      if (c2 == EVQL_EMPTY && claim) {
+        c2 = atomicCAS((unsigned long long*) (key + 1), (unsigned long long) EVQL_EMPTY,
+                       (unsigned long long) rec[2]);
+        if (c2 == EVQL_EMPTY) c2 = rec[2];
+      }
+      if (c2 == rec[2]) return (int) s;
+    }
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+// One workgroup per bucket: its records are merged in an LDS table (states with LDS
+// atomics, the first row by its smallest (rank << 44 | row) word, whose record then supplies
+// the first-row values) and the occupied slots leave as dense records.
+__global__ void __launch_bounds__(kBlock) k_bucket_merge(BucketMergeArgs a) {
+  extern __shared__ u64 tab[];  // (lds_slots + 2) x mw words
+  __shared__ u64 base_s;
+  const u32 tid = threadIdx.x;
+  const u32 rw = a.mw + 1;
+  const u32 nslots = a.lds_slots + 2;
+  for (u32 b = blockIdx.x; b < a.buckets; b += gridDim.x) {
+    u64 cnt = a.counts[b];
+    if (cnt > a.region_cap) cnt = a.region_cap;
+    if (cnt == 0) continue;  // (uniform)
+    for (u32 i = tid; i < nslots * a.mw; i += kBlock) tab[i] = a.identity[i % a.mw];
+    __syncthreads();
+    const u64* recs = (const u64*) a.stage + (u64) b * a.region_cap * rw;
+    for (u64 i = tid; i < cnt; i += kBlock) {
+      const u64* rec = recs + i * rw;
+      const int s = bucket_find(tab, a, rec, true);
+      if (s < 0) {
+        atomicOr(a.status, 1u);
+        continue;
+      }
+      u64* slot = tab + (u64) s * a.mw;
+      for (u32 w = 1 + a.has_ident2; w < a.state_words; ++w) {
+        if (w == a.first_row_word) {
+          atomicMin((unsigned long long*) &slot[w], (unsigned long long) rec[1 + w]);
+        } else {
+          rt_atomic(a.ops[w], &slot[w], rec[1 + w]);
+        }
+      }
+    }
+    if (a.first_row_word != 0xffffffffu) {
+      __syncthreads();
+      for (u64 i = tid; i < cnt; i += kBlock) {
+        const u64* rec = recs + i * rw;
+        const int s = bucket_find(tab, a, rec, false);
+        if (s < 0) continue;
+        u64* slot = tab + (u64) s * a.mw;
+        // (rank << 44 | row) is unique: one record per group owns the first row
+        if (evql_lds_peek(&slot[a.first_row_word]) != rec[1 + a.first_row_word]) continue;
+        for (u32 c = 0; c <= a.ncols; ++c) slot[a.state_words + c] = rec[1 + a.state_words + c];
+      }
+    }
+    __syncthreads();
+    const u32 rounds = (nslots + kBlock - 1) / kBlock;
+    for (u32 it = 0; it < rounds; ++it) {
+      const u32 s = it * kBlock + tid;
+      const u64 k = s < nslots ? tab[(u64) s * a.mw] : EVQL_EMPTY;
+      const bool occ = k != EVQL_EMPTY;
+      u32 total;
+      const u32 ex = block_excl_scan(occ ? 1u : 0u, &total);
+      if (tid == 0) base_s = total ? atomicAdd((unsigned long long*) a.out_count, (unsigned long long) total) : 0;
+      __syncthreads();
+      const u64 idx = base_s + ex;
+      __syncthreads();
+      if (!occ || idx >= a.out_cap) continue;
+      u64* rec = (u64*) a.out + idx * rw;
+      rec[0] = s == a.lds_slots ? 1ull : (s == a.lds_slots + 1 ? 2ull : 0ull);
+      rec[1] = s == a.lds_slots ? EVQL_EMPTY : k;
+      for (u32 w = 1; w < a.mw; ++w) rec[1 + w] = tab[(u64) s * a.mw + w];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- block-wide helpers -----------------------------------------------------------
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 #pragma unroll
@@ -1955,6 +2159,19 @@ hipError_t launch_wire_str_sizes(const WireStrArgs& a, hipStream_t s) {
 hipError_t launch_wire_str_copy(const WireStrArgs& a, hipStream_t s) {
   if (a.n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_wire_str_copy, dim3(grid_for(a.n)), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_bucket_scatter(const BucketScatterArgs& a, hipStream_t s) {
+  const u64 vtiles = (u64) a.in_regions * a.tiles_per_region;
+  const size_t lds = (size_t) a.tile * a.rw * 8;
+  hipLaunchKernelGGL(k_bucket_scatter, dim3(grid_for(vtiles * kBlock, kBlock, 16384)), dim3(kBlock), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_bucket_merge(const BucketMergeArgs& a, hipStream_t s) {
+  const size_t lds = (size_t) (a.lds_slots + 2) * a.mw * 8;
+  hipLaunchKernelGGL(k_bucket_merge, dim3(a.buckets < 65536 ? a.buckets : 65536), dim3(kBlock), lds, s, a);
   return hipGetLastError();
 }
 

@@ -72,7 +72,7 @@ struct evql_exchange {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Slot ws[16];
+  Slot ws[20];
   hipError_t get(int slot, size_t bytes, void** out) {
     Slot& sl = ws[slot];
     if (bytes > sl.cap) {
@@ -327,6 +327,137 @@ static Status exchange_pairset(evql_query* q, evql_exchange* x, bool by_owner, i
   pa.key_mode = uint32_t(q->kp.key_mode);
   pa.status = q->d_status;
   HIP_TRY(launch_pairset_merge(pa, d_recv, total, s));
+  return Status();
+}
+
+// -----------------------------------------------------------------------------------------
+// large merges: split by identity hash into LDS-sized buckets, merge every bucket in the LDS
+// -----------------------------------------------------------------------------------------
+// Merging 1e7 received records into an HBM hash table costs 2.1 ms however few atomics a
+// record needs (scattered line accesses over a > 1 GB table).  From kBucketedMergeMin
+// records on, the records take two LDS-staged scatter passes (<= 256 bins each, regions
+// with slack instead of a histogram pass) and one LDS merge per bucket, and the merged
+// groups stay with the query as dense records (q->d_mdense).  *done = false: the shape
+// does not fit (count_distinct needs the table for its lookups, records too wide for a
+// tile / an LDS table) or a region outgrew its slack -- the caller merges through the table.
+static const uint64_t kBucketedMergeMin = 1ull << 18;
+
+static Status bucketed_merge(evql_query* q, evql_exchange* x, const MergeResolvedArgs& ma,
+                             const uint64_t* identity, const uint64_t* d_recv,
+                             const std::vector<uint64_t>& recv_rec,
+                             const std::vector<uint64_t>& hbase, uint64_t total_rec, bool* done) {
+  *done = false;
+  hipStream_t s = q->ctx->stream;
+  const uint32_t mw = ma.m.nwords, rw = mw + 1;
+  if (total_rec < kBucketedMergeMin || recv_rec.size() > kMaxExchangeRanks) return Status();
+  // LDS table of a bucket: <= 60 KB, power of two slots + the two keyless groups
+  uint32_t slots = 1;
+  while (uint64_t(slots * 2 + 2) * mw * 8 <= 60 * 1024) slots *= 2;
+  if (slots < 64) return Status();
+  uint32_t tile = uint32_t((56 * 1024) / (rw * 8)) / 256 * 256;
+  if (tile > 2048) tile = 2048;
+  if (tile < 256) return Status();
+  int nsrc = 0;
+  for (uint64_t c : recv_rec) nsrc += c ? 1 : 0;
+  // buckets: a power of two with <= slots / 3 records on average, two levels of <= 256 bins
+  uint32_t fbits = 1;
+  while ((total_rec >> fbits) > slots / 3) ++fbits;
+  const uint32_t c1_bits = (fbits + 1) / 2, c2_bits = fbits - c1_bits;
+  if (c1_bits > 8) return Status();
+  const uint32_t C1 = 1u << c1_bits, C2 = 1u << c2_bits;
+  const uint64_t F = uint64_t(C1) * C2;
+  // a group arrives once per source rank: the spread of a region is that of nsrc-fold copies
+  auto region_cap = [&](double avg, double floor_) {
+    return uint64_t(avg + 6.0 * std::sqrt(avg * std::max(nsrc, 1)) + floor_);
+  };
+  const uint64_t cap1 = region_cap(double(total_rec) / C1, 1024);
+  const uint64_t cap2 = region_cap(double(total_rec) / double(F), 64);
+  WsBuf<uint64_t> d_stage1(x, 14), d_stage2(x, 15), d_cur(x, 16);
+  HIP_TRY(d_stage1.alloc(uint64_t(C1) * cap1 * rw * 8));
+  HIP_TRY(d_stage2.alloc(F * cap2 * rw * 8));
+  HIP_TRY(d_cur.alloc((C1 + F + 2) * 8));
+  HIP_TRY(hipMemsetAsync(d_cur, 0, (C1 + F + 2) * 8, s));
+  uint64_t* d_cnt1 = d_cur.p;
+  uint64_t* d_cnt2 = d_cur.p + C1;
+  uint64_t* d_out_count = d_cur.p + C1 + F;
+  uint32_t* d_flag = reinterpret_cast<uint32_t*>(d_cur.p + C1 + F + 1);
+  if (q->mdense_cap < total_rec) {
+    if (q->d_mdense) hipFree(q->d_mdense);
+    q->d_mdense = nullptr;
+    q->mdense_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mdense), total_rec * rw * 8));
+    q->mdense_cap = total_rec;
+  }
+  BucketScatterArgs sa{};
+  sa.in = d_recv;
+  sa.out = d_stage1;
+  sa.in_counts = nullptr;
+  sa.n_in = total_rec;
+  sa.in_region_cap = total_rec;
+  sa.in_regions = 1;
+  sa.tiles_per_region = uint32_t((total_rec + tile - 1) / tile);
+  sa.tile = tile;
+  sa.rw = rw;
+  sa.rw_inv = uint32_t(((1ull << 32) + rw - 1) / rw);
+  sa.shift = 64 - c1_bits;
+  sa.bins = C1;
+  sa.out_region_cap = cap1;
+  sa.out_counts = d_cnt1;
+  sa.status = d_flag;
+  sa.first_value_word = 1 + ma.state_words;
+  sa.ncols = ma.ncols;
+  sa.str_mask = ma.str_mask;
+  sa.nranks = uint32_t(recv_rec.size());
+  uint64_t off = 0;
+  for (size_t r = 0; r < recv_rec.size(); ++r) {
+    sa.rank_start[r] = off;
+    sa.heap_base[r] = hbase[r];
+    off += recv_rec[r];
+  }
+  sa.rank_start[recv_rec.size()] = off;
+  HIP_TRY(launch_bucket_scatter(sa, s));
+  BucketScatterArgs sb = sa;
+  sb.in = d_stage1;
+  sb.out = d_stage2;
+  sb.in_counts = d_cnt1;
+  sb.in_region_cap = cap1;
+  sb.in_regions = C1;
+  sb.tiles_per_region = uint32_t((cap1 + tile - 1) / tile);
+  sb.shift = 64 - c1_bits - c2_bits;
+  sb.bins = C2;
+  sb.out_region_cap = cap2;
+  sb.out_counts = d_cnt2;
+  sb.nranks = 0;
+  sb.str_mask = 0;
+  HIP_TRY(launch_bucket_scatter(sb, s));
+  BucketMergeArgs ba{};
+  ba.stage = d_stage2;
+  ba.counts = d_cnt2;
+  ba.region_cap = cap2;
+  ba.buckets = uint32_t(F);
+  ba.mw = mw;
+  ba.has_ident2 = ma.m.has_ident2;
+  ba.state_words = ma.state_words;
+  ba.first_row_word = ma.first_row_word;
+  ba.ncols = ma.first_row_word == 0xffffffffu ? 0 : ma.ncols;
+  ba.lds_slots = slots;
+  for (uint32_t w = 0; w < mw; ++w) {
+    ba.ops[w] = ma.m.ops[w];
+    ba.identity[w] = identity[w];
+  }
+  ba.out = q->d_mdense;
+  ba.out_cap = q->mdense_cap;
+  ba.out_count = d_out_count;
+  ba.status = d_flag;
+  HIP_TRY(launch_bucket_merge(ba, s));
+  uint64_t tail[2] = {0, 0};  // [groups, flag]
+  HIP_TRY(hipMemcpyAsync(tail, d_out_count, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (tail[1] & 0xffffffffull) return Status();  // (a region / an LDS table overflowed)
+  q->mdense_n = tail[0];
+  q->merged_dense = true;
+  x->stats.merge_buckets = F;
+  *done = true;
   return Status();
 }
 
@@ -599,18 +730,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
 
   // ---- 6. merge, one batch per source rank, in rank order, into a fresh table --------------------
   const uint32_t mw = resolved ? W + nc + 1 : W;  // slot words of the merged table
-  uint64_t cap = 1 << 16;
-  while (cap < total_rec * 2) cap <<= 1;
-  if (!q->d_mtab || q->mcap != cap || q->m_words != mw) {
-    if (q->d_mtab) hipFree(q->d_mtab);
-    q->d_mtab = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mtab), (cap + 8) * uint64_t(mw) * 8));
-  }
-  q->mcap = cap;
-  q->m_words = mw;
   TableInitArgs ia{};
-  ia.words = q->d_mtab;
-  ia.stride = cap + 8;
   ia.nwords = mw;
   ia.identity[0] = 0xFFFFFFFFFFFFFFFFull;
   int w = 1;
@@ -621,11 +741,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
                                      0xFFF0000000000000ull};
   for (const auto& sw : kp.states) ia.identity[w++] = kIdent[sw.op & 7];
   for (; w < int(mw); ++w) ia.identity[w] = 0;
-  HIP_TRY(launch_table_init(ia, s));
   MergeResolvedArgs ma{};
-  ma.m.words = q->d_mtab;
-  ma.m.gcap = cap;
-  ma.m.stride = cap + 8;
   ma.m.nwords = mw;
   ma.m.has_ident2 = kp.has_ident2() ? 1 : 0;
   w = 1;
@@ -634,33 +750,66 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   for (const auto& sw : kp.states) ma.m.ops[w++] = uint32_t(sw.op);
   // a count_distinct word counts the pairs of the MERGED set: foreign counts are not
   // added, the pairs are exchanged below and counted again
+  bool has_distinct = false;
   for (const auto& ag : kp.aggs) {
-    if (ag.distinct_index >= 0) ma.m.ops[kp.state_word_base() + ag.first_word] = kMergeSkip;
+    if (ag.distinct_index >= 0) {
+      ma.m.ops[kp.state_word_base() + ag.first_word] = kMergeSkip;
+      has_distinct = true;
+    }
   }
   ma.m.status = q->d_status;
   ma.state_words = W;
   ma.first_row_word = resolved ? uint32_t(kp.first_row_word()) : 0xffffffffu;
   ma.ncols = nc;
   ma.str_mask = str_mask;
-  // the records of one source rank are its groups: pairwise different identities, one
-  // launch per rank -- plain read-modify-write behind the identity CAS (1e7 records:
-  // 4 scattered HBM atomics each took 2.1 ms), new slots counted as they are claimed
-  uint64_t* d_ngroups = q->d_counters + 4;
-  ma.m.exclusive = 1;
-  ma.m.fresh = d_ngroups;
-  HIP_TRY(hipMemsetAsync(d_ngroups, 0, 8, s));
   HIP_TRY(hipMemsetAsync(q->d_status, 0, 16, s));
-  uint64_t roff = 0;
-  for (int r = 0; r < N; ++r) {
-    if (recv_rec[r]) {
-      if (resolved) {
-        ma.heap_base = hbase[r];
-        HIP_TRY(launch_table_merge_resolved(ma, d_recv.p + roff * rw, recv_rec[r], s));
-      } else {
-        HIP_TRY(launch_table_merge(ma.m, d_recv.p + roff * rw, recv_rec[r], s));
-      }
+  q->merged_dense = false;
+  uint64_t ng = 0;
+  uint64_t cap = 0;
+  bool bucketed = false;
+  if (!has_distinct) {
+    Status stb = bucketed_merge(q, x, ma, ia.identity, d_recv, recv_rec, hbase, total_rec, &bucketed);
+    if (!stb.ok()) return stb;
+  }
+  if (bucketed) {
+    ng = q->mdense_n;
+    q->m_words = mw;
+  } else {
+    cap = 1 << 16;
+    while (cap < total_rec * 2) cap <<= 1;
+    if (!q->d_mtab || q->mcap != cap || q->m_words != mw) {
+      if (q->d_mtab) hipFree(q->d_mtab);
+      q->d_mtab = nullptr;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_mtab), (cap + 8) * uint64_t(mw) * 8));
     }
-    roff += recv_rec[r];
+    q->mcap = cap;
+    q->m_words = mw;
+    ia.words = q->d_mtab;
+    ia.stride = cap + 8;
+    HIP_TRY(launch_table_init(ia, s));
+    ma.m.words = q->d_mtab;
+    ma.m.gcap = cap;
+    ma.m.stride = cap + 8;
+    // the records of one source rank are its groups: pairwise different identities, one
+    // launch per rank -- plain read-modify-write behind the identity CAS, new slots counted
+    // as they are claimed
+    uint64_t* d_ngroups = q->d_counters + 4;
+    ma.m.exclusive = 1;
+    ma.m.fresh = d_ngroups;
+    HIP_TRY(hipMemsetAsync(d_ngroups, 0, 8, s));
+    uint64_t roff = 0;
+    for (int r = 0; r < N; ++r) {
+      if (recv_rec[r]) {
+        if (resolved) {
+          ma.heap_base = hbase[r];
+          HIP_TRY(launch_table_merge_resolved(ma, d_recv.p + roff * rw, recv_rec[r], s));
+        } else {
+          HIP_TRY(launch_table_merge(ma.m, d_recv.p + roff * rw, recv_rec[r], s));
+        }
+      }
+      roff += recv_rec[r];
+    }
+    HIP_TRY(hipMemcpyAsync(&ng, d_ngroups, 8, hipMemcpyDeviceToHost, s));
   }
   // ---- 7. count_distinct: the pair sets follow their groups --------------------------------------
   for (const auto& ag : kp.aggs) {
@@ -671,8 +820,6 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   }
   uint32_t status[4] = {0};
   HIP_TRY(hipMemcpyAsync(status, q->d_status, 16, hipMemcpyDeviceToHost, s));
-  uint64_t ng = 0;
-  HIP_TRY(hipMemcpyAsync(&ng, d_ngroups, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (status[0] & 2u) return Status::error(EVQL_ENOMEM, "merged group table full");
   if (status[0] & 8u) return Status::error(EVQL_ENOMEM, "merged count_distinct set full");

@@ -317,6 +317,7 @@ evql_query::~evql_query() {
   if (d_part_cursors) hipFree(d_part_cursors);
   if (d_dense) hipFree(d_dense);
   if (d_mtab) hipFree(d_mtab);
+  if (d_mdense) hipFree(d_mdense);
   if (d_conv) hipFree(d_conv);
   for (auto* p : demit.col) {
     if (p) hipHostFree(p);
@@ -1888,6 +1889,7 @@ Status query_launch(evql_query* q) {
   }
   q->probed = true;
   q->merged = false;
+  q->merged_dense = false;
   q->conv_valid = false;
   const KernelPlan& kp = q->kp;
   hipStream_t s = ctx->stream;
@@ -2393,6 +2395,7 @@ Status query_reset(evql_query* q) {
   q->ngroups = 0;
   q->dense_n = 0;
   q->merged = false;
+  q->merged_dense = false;
   q->stats.num_groups = 0;
   q->stats.rows_scanned = 0;
   q->stats.rows_passed = 0;
@@ -2600,7 +2603,7 @@ static Status fetch_results(evql_query* q) {
   const bool merged = q->merged;
   const uint32_t nwords = merged ? q->m_words : uint32_t(kp.words_per_slot());
   uint64_t* const gtab = merged ? q->d_mtab : q->d_gtab;
-  const uint64_t gcap = merged ? q->mcap : q->gcap;
+  const uint64_t gcap = merged ? (q->merged_dense ? q->mdense_n : q->mcap) : q->gcap;
   const uint64_t stride = gcap + 8;
   const uint64_t maxrec = gcap + 2;
   RecordsView view;
@@ -2620,7 +2623,11 @@ static Status fetch_results(evql_query* q) {
   // inside a step
   const size_t kSmallRec = 1 << 20;
   DevBuf<uint64_t> rec_own;  // records that do not fit the small buffer
-  if (n) {
+  if (n && merged && q->merged_dense) {
+    // (a bucketed merge left the groups as dense records already)
+    n = std::min(n, q->mdense_n);
+    d_rec = q->d_mdense;
+  } else if (n) {
     if (n * (nwords + 1) * 8 <= kSmallRec) {
       if (!q->d_small_rec) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&q->d_small_rec), kSmallRec));
       d_rec = q->d_small_rec;

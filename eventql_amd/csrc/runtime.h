@@ -277,6 +277,12 @@ struct evql_query {
   uint64_t mcap = 0;
   uint32_t m_words = 0;
   std::vector<uint8_t> m_heap;  // received string bytes
+  // large merges (exchange.cc bucketed_merge) leave dense records [kind, slot words...]
+  // instead of a table
+  bool merged_dense = false;
+  uint64_t* d_mdense = nullptr;
+  uint64_t mdense_cap = 0;  // records
+  uint64_t mdense_n = 0;
   int n_update_words = 0;   // update words per row (tuple payload)
   // nested (Dremel) scans: flattened per-row SoA columns, one per scan column
   bool nested = false;

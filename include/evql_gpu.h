@@ -630,7 +630,9 @@ typedef enum {
  * partition): exports this rank's groups, exchanges them and merges what arrives
  * (mergeInstance per aggregate, groupby.cc:577-612) -- batches in RANK ORDER into a
  * fresh table, so that a float sum is added up in the same order on every rank and
- * in every run of the same partial aggregates.  Plans that read first-row values
+ * in every run of the same partial aggregates (record sets of 2^18 records and more are
+ * merged bucket by bucket in the LDS instead -- no scattered HBM accesses; there only
+ * EVQL_FLOAT_SUM_EXACT sums are independent of the order).  Plans that read first-row values
  * (string / multi-column keys, non-aggregate select expressions) carry them in the
  * records: the first row of the lowest rank that has the group wins, strings travel
  * as bytes.  next_batch then yields the merged groups.  count_distinct: the (group,
@@ -645,6 +647,8 @@ typedef struct {
   uint64_t groups_received; /* records merged here (own ones included) */
   uint64_t bytes_sent;      /* record + string bytes that left this rank */
   double export_ms, transfer_ms, merge_ms;
+  uint64_t merge_buckets;   /* != 0: merged in the LDS, bucket by bucket (large record sets);
+                               0: merged through an HBM table, one launch per source rank */
 } evql_exchange_stats_t;
 int evql_exchange_last_stats(const evql_exchange_t* x, evql_exchange_stats_t* out);
 

@@ -340,3 +340,71 @@ def test_partial_rows_with_count_distinct_after_an_exchange(name):
         assert sorted(rows) == want
     res = run_ranks(3, parts, pkw, K.EXCHANGE_BY_OWNER)
     assert sorted(r for rows, _, _ in res for r in rows) == want
+
+
+def big_partition(seed, n, spread):
+    c = partition(seed, n)
+    rng = np.random.default_rng(seed + 77)
+    c["u"] = rng.integers(0, spread, n, dtype=np.uint64)
+    c["s"] = [b"key-%d" % x for x in c["u"]]
+    return c
+
+
+BIG_PLANS = {
+    # config 4's shape: exact u64 identities, integer and float states
+    "u64-key": dict(select=[col("u"), count(1), sum_(col("a")), sum_(col("v")), min_(col("v")),
+                            max_(col("a"))], group_by=[col("u")], groups_hint=500_000),
+    # config 4s': string keys -- first rows resolved by the sender, bytes in the heap
+    "string-key": dict(select=[col("s"), count(1), sum_(col("a"))], group_by=[col("s")],
+                       groups_hint=500_000),
+    # two key columns: 128-bit hashed identities, key values from the first row
+    "two-keys": dict(select=[col("u"), col("k"), count(1), max_(col("a"))],
+                     group_by=[col("u"), col("k")], key_cols=2, groups_hint=500_000),
+    "exact-sums": dict(select=[col("u"), sum_(col("v")), count(1)], group_by=[col("u")],
+                       groups_hint=500_000, float_sum_mode=K.FLOAT_SUM_EXACT, float_sum_bound=1024.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BIG_PLANS))
+def test_large_record_sets_are_merged_bucket_by_bucket(name):
+    """>= 2^18 received records: split by identity hash into LDS-sized buckets and merged
+    there (k_bucket_scatter x 2, k_bucket_merge) instead of through an HBM table; the
+    result is the same set of groups"""
+    kw = dict(BIG_PLANS[name])
+    kc = kw.pop("key_cols", 1)
+    nranks = 3
+    parts = [big_partition(300 + r, 340_000 + 10_000 * r, 1_500_000) for r in range(nranks)]
+    exp = O.oracle_run(image_of(parts), Plan(S, **kw))
+    res = run_ranks(nranks, parts, kw, K.EXCHANGE_BY_OWNER)
+    assert all(st["merge_buckets"] > 0 for _, _, st in res), [st for _, _, st in res]
+    union = [row for rows, _, _ in res for row in rows]
+    assert len(union) == exp.nrows
+    T.compare_results(union, exp.rows(), exp.types, key_cols=kc, rel=1e-9)
+    res = run_ranks(nranks, parts, kw, K.EXCHANGE_GATHER_ALL)
+    assert all(st["merge_buckets"] > 0 for _, _, st in res)
+    for rows, _, _ in res[:2]:
+        assert len(rows) == exp.nrows
+        T.compare_results(rows, exp.rows(), exp.types, key_cols=kc, rel=1e-9)
+    if name == "exact-sums":
+        canon = [sorted(map(repr, r[0])) for r in res]
+        assert all(c == canon[0] for c in canon[1:])
+
+
+def test_first_rows_survive_a_bucketed_merge():
+    """the first-row values of a group come from the lowest rank that has it, also when the
+    records are merged in the LDS (the record with the smallest (rank << 44 | row) word)"""
+    parts = [big_partition(400 + r, 300_000, 600_000) for r in range(2)]
+    kw = dict(select=[col("u"), col("s"), col("a"), count(1)], group_by=[col("u")],
+              groups_hint=400_000)
+    res = run_ranks(2, parts, kw, K.EXCHANGE_GATHER_ALL)
+    assert all(st["merge_buckets"] > 0 for _, _, st in res)
+    exp0 = O.oracle_run(image_of([parts[0]]), Plan(S, **kw))
+    exp1 = O.oracle_run(image_of([parts[1]]), Plan(S, **kw))
+    first = {r[0]: (r[1], r[2]) for r in exp1.rows()}
+    first.update({r[0]: (r[1], r[2]) for r in exp0.rows()})
+    both = O.oracle_run(image_of(parts), Plan(S, **kw))
+    counts = {r[0]: r[3] for r in both.rows()}
+    rows = res[1][0]
+    assert len(rows) == both.nrows
+    for u, s, a, c in rows:
+        assert c == counts[u] and (s, a) == first[u]
