@@ -575,13 +575,15 @@ __global__ void __launch_bounds__(kBlock) k_bucket_scatter(BucketScatterArgs a) 
 }
 
 // slot of a record's group in the LDS table of its bucket; `claim`: insert when new
+// (*fresh: this call claimed the slot)
 __device__ __forceinline__ int bucket_find(u64* tab, const BucketMergeArgs& a, const u64* rec,
-                                           bool claim) {
+                                           bool claim, bool* fresh) {
   const u64 kind = rec[0];
+  *fresh = false;
   if (kind != 0) {
     u64* key = tab + (u64) (a.lds_slots + (u32) kind - 1) * a.mw;
     if (claim) {
-      *key = 0;
+      *fresh = atomicExch((unsigned long long*) key, 0ull) == EVQL_EMPTY;
     } else if (evql_lds_peek(key) == EVQL_EMPTY) {
       return -1;
     }
@@ -594,22 +596,36 @@ __device__ __forceinline__ int bucket_find(u64* tab, const BucketMergeArgs& a, c
   for (u32 probe = 0; probe < a.lds_slots; ++probe) {
     u64* key = tab + (u64) s * a.mw;
     u64 cur = evql_lds_peek(key);
+    bool claimed = false;
     if (cur == EVQL_EMPTY) {
       if (!claim) return -1;
       cur = atomicCAS((unsigned long long*) key, (unsigned long long) EVQL_EMPTY, (unsigned long long) ident);
-      if (cur == EVQL_EMPTY) cur = ident;
+      if (cur == EVQL_EMPTY) {
+        cur = ident;
+        claimed = true;
+      }
     }
     if (cur == ident) {
-      if (!a.has_ident2) return (int) s;
+      if (!a.has_ident2) {
+        *fresh = claimed;
+        return (int) s;
+      }
       // (the protocol of evql_gtab_find2: two keys that agree in the first word race for
       // the second one, the loser moves on along the chain)
       u64 c2 = evql_lds_peek(key + 1);
+      bool claimed2 = false;
       if (c2 == EVQL_EMPTY && claim) {
         c2 = atomicCAS((unsigned long long*) (key + 1), (unsigned long long) EVQL_EMPTY,
                        (unsigned long long) rec[2]);
-        if (c2 == EVQL_EMPTY) c2 = rec[2];
+        if (c2 == EVQL_EMPTY) {
+          c2 = rec[2];
+          claimed2 = true;
+        }
       }
-      if (c2 == rec[2]) return (int) s;
+      if (c2 == rec[2]) {
+        *fresh = claimed2;
+        return (int) s;
+      }
     }
     s = (s + 1) & mask;
   }
@@ -618,27 +634,37 @@ __device__ __forceinline__ int bucket_find(u64* tab, const BucketMergeArgs& a, c
 
 // One workgroup per bucket: its records are merged in an LDS table (states with LDS
 // atomics, the first row by its smallest (rank << 44 | row) word, whose record then supplies
-// the first-row values) and the occupied slots leave as dense records.
+// the first-row values) and the occupied slots leave as dense records.  The thread that
+// claims a slot numbers it, so the bucket reserves its output run with ONE add to the global
+// counter (a block scan + an add per 256 slots: 1.6 ms of same-address atomics for 3e4 buckets).
 __global__ void __launch_bounds__(kBlock) k_bucket_merge(BucketMergeArgs a) {
-  extern __shared__ u64 tab[];  // (lds_slots + 2) x mw words
+  extern __shared__ u64 tab[];  // (lds_slots + 2) x mw words, then one u32 per slot
   __shared__ u64 base_s;
+  __shared__ u32 nclaimed;
   const u32 tid = threadIdx.x;
   const u32 rw = a.mw + 1;
   const u32 nslots = a.lds_slots + 2;
+  u32* order = (u32*) (tab + (u64) nslots * a.mw);
   for (u32 b = blockIdx.x; b < a.buckets; b += gridDim.x) {
     u64 cnt = a.counts[b];
     if (cnt > a.region_cap) cnt = a.region_cap;
     if (cnt == 0) continue;  // (uniform)
-    for (u32 i = tid; i < nslots * a.mw; i += kBlock) tab[i] = a.identity[i % a.mw];
+    for (u32 sl = tid; sl < nslots; sl += kBlock) {
+      u64* slot = tab + (u64) sl * a.mw;
+      for (u32 w = 0; w < a.mw; ++w) slot[w] = a.identity[w];
+    }
+    if (tid == 0) nclaimed = 0;
     __syncthreads();
     const u64* recs = (const u64*) a.stage + (u64) b * a.region_cap * rw;
     for (u64 i = tid; i < cnt; i += kBlock) {
       const u64* rec = recs + i * rw;
-      const int s = bucket_find(tab, a, rec, true);
+      bool fresh;
+      const int s = bucket_find(tab, a, rec, true, &fresh);
       if (s < 0) {
         atomicOr(a.status, 1u);
         continue;
       }
+      if (fresh) order[s] = atomicAdd(&nclaimed, 1u);
       u64* slot = tab + (u64) s * a.mw;
       for (u32 w = 1 + a.has_ident2; w < a.state_words; ++w) {
         if (w == a.first_row_word) {
@@ -652,7 +678,8 @@ __global__ void __launch_bounds__(kBlock) k_bucket_merge(BucketMergeArgs a) {
       __syncthreads();
       for (u64 i = tid; i < cnt; i += kBlock) {
         const u64* rec = recs + i * rw;
-        const int s = bucket_find(tab, a, rec, false);
+        bool fresh;
+        const int s = bucket_find(tab, a, rec, false, &fresh);
         if (s < 0) continue;
         u64* slot = tab + (u64) s * a.mw;
         // (rank << 44 | row) is unique: one record per group owns the first row
@@ -661,22 +688,20 @@ __global__ void __launch_bounds__(kBlock) k_bucket_merge(BucketMergeArgs a) {
       }
     }
     __syncthreads();
-    const u32 rounds = (nslots + kBlock - 1) / kBlock;
-    for (u32 it = 0; it < rounds; ++it) {
-      const u32 s = it * kBlock + tid;
-      const u64 k = s < nslots ? tab[(u64) s * a.mw] : EVQL_EMPTY;
-      const bool occ = k != EVQL_EMPTY;
-      u32 total;
-      const u32 ex = block_excl_scan(occ ? 1u : 0u, &total);
-      if (tid == 0) base_s = total ? atomicAdd((unsigned long long*) a.out_count, (unsigned long long) total) : 0;
-      __syncthreads();
-      const u64 idx = base_s + ex;
-      __syncthreads();
-      if (!occ || idx >= a.out_cap) continue;
+    if (tid == 0) {
+      base_s = nclaimed ? atomicAdd((unsigned long long*) a.out_count, (unsigned long long) nclaimed) : 0;
+    }
+    __syncthreads();
+    const u64 base = base_s;
+    for (u32 sl = tid; sl < nslots; sl += kBlock) {
+      const u64 k = tab[(u64) sl * a.mw];
+      if (k == EVQL_EMPTY) continue;
+      const u64 idx = base + order[sl];
+      if (idx >= a.out_cap) continue;
       u64* rec = (u64*) a.out + idx * rw;
-      rec[0] = s == a.lds_slots ? 1ull : (s == a.lds_slots + 1 ? 2ull : 0ull);
-      rec[1] = s == a.lds_slots ? EVQL_EMPTY : k;
-      for (u32 w = 1; w < a.mw; ++w) rec[1 + w] = tab[(u64) s * a.mw + w];
+      rec[0] = sl == a.lds_slots ? 1ull : (sl == a.lds_slots + 1 ? 2ull : 0ull);
+      rec[1] = sl == a.lds_slots ? EVQL_EMPTY : k;
+      for (u32 w = 1; w < a.mw; ++w) rec[1 + w] = tab[(u64) sl * a.mw + w];
     }
     __syncthreads();
   }
@@ -2170,7 +2195,7 @@ hipError_t launch_bucket_scatter(const BucketScatterArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_bucket_merge(const BucketMergeArgs& a, hipStream_t s) {
-  const size_t lds = (size_t) (a.lds_slots + 2) * a.mw * 8;
+  const size_t lds = (size_t) (a.lds_slots + 2) * a.mw * 8 + (size_t) (a.lds_slots + 2) * 4;
   hipLaunchKernelGGL(k_bucket_merge, dim3(a.buckets < 65536 ? a.buckets : 65536), dim3(kBlock), lds, s, a);
   return hipGetLastError();
 }

@@ -350,9 +350,10 @@ static Status bucketed_merge(evql_query* q, evql_exchange* x, const MergeResolve
   hipStream_t s = q->ctx->stream;
   const uint32_t mw = ma.m.nwords, rw = mw + 1;
   if (total_rec < kBucketedMergeMin || recv_rec.size() > kMaxExchangeRanks) return Status();
-  // LDS table of a bucket: <= 60 KB, power of two slots + the two keyless groups
+  // LDS table of a bucket: <= 60 KB (30 KB tables = twice the buckets measured slower: 1.44 vs
+  // 1.05 ms per 1e7 records), power of two slots + the two keyless groups
   uint32_t slots = 1;
-  while (uint64_t(slots * 2 + 2) * mw * 8 <= 60 * 1024) slots *= 2;
+  while (uint64_t(slots * 2 + 2) * (mw * 8 + 4) <= 60 * 1024) slots *= 2;
   if (slots < 64) return Status();
   uint32_t tile = uint32_t((56 * 1024) / (rw * 8)) / 256 * 256;
   if (tile > 2048) tile = 2048;
@@ -416,6 +417,7 @@ static Status bucketed_merge(evql_query* q, evql_exchange* x, const MergeResolve
   }
   sa.rank_start[recv_rec.size()] = off;
   HIP_TRY(launch_bucket_scatter(sa, s));
+  const bool two_levels = c2_bits > 0;
   BucketScatterArgs sb = sa;
   sb.in = d_stage1;
   sb.out = d_stage2;
@@ -429,11 +431,11 @@ static Status bucketed_merge(evql_query* q, evql_exchange* x, const MergeResolve
   sb.out_counts = d_cnt2;
   sb.nranks = 0;
   sb.str_mask = 0;
-  HIP_TRY(launch_bucket_scatter(sb, s));
+  if (two_levels) HIP_TRY(launch_bucket_scatter(sb, s));
   BucketMergeArgs ba{};
-  ba.stage = d_stage2;
-  ba.counts = d_cnt2;
-  ba.region_cap = cap2;
+  ba.stage = two_levels ? d_stage2.p : d_stage1.p;
+  ba.counts = two_levels ? d_cnt2 : d_cnt1;
+  ba.region_cap = two_levels ? cap2 : cap1;
   ba.buckets = uint32_t(F);
   ba.mw = mw;
   ba.has_ident2 = ma.m.has_ident2;
@@ -507,18 +509,25 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   // ---- 1. this rank's groups as dense records ---------------------------------------------
   const uint64_t n = q->ngroups;
   WsBuf<uint64_t> d_rec(x, 0);
-  HIP_TRY(d_rec.alloc(std::max<uint64_t>(n, 1) * rw_in * 8));
+  const uint64_t* d_records = nullptr;  // n records of rw_in words
   {
     RecordsView view;
     Status stv = query_records_view(q, &view);
     if (!stv.ok()) return stv;
     const uint64_t nd = view.nd;
-    if (nd) HIP_TRY(hipMemcpyAsync(d_rec, view.dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
-    if (n > nd) {
-      uint64_t* d_cnt = q->d_counters + 6;
-      HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
-      HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, W, d_rec.p + nd * rw_in, n - nd,
-                                   d_cnt, s));
+    if (n && nd == n) {
+      // (the partitioned path left every group as a dense record: read in place)
+      d_records = view.dense;
+    } else {
+      HIP_TRY(d_rec.alloc(std::max<uint64_t>(n, 1) * rw_in * 8));
+      if (nd) HIP_TRY(hipMemcpyAsync(d_rec, view.dense, nd * rw_in * 8, hipMemcpyDeviceToDevice, s));
+      if (n > nd) {
+        uint64_t* d_cnt = q->d_counters + 6;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, s));
+        HIP_TRY(launch_table_compact(q->d_gtab, q->gcap, q->gcap + 8, W, d_rec.p + nd * rw_in, n - nd,
+                                     d_cnt, s));
+      }
+      d_records = d_rec;
     }
   }
   // ---- 2. first-row values into the records (plans that need them) -------------------------
@@ -564,18 +573,19 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     ra.in_words = rw_in;
     ra.first_row_word = uint32_t(1 + kp.first_row_word());
     ra.rank_tag = uint64_t(x->rank) << 44;
-    ra.in = d_rec;
+    ra.in = d_records;
     ra.n = n;
     ra.out = d_wire;
     HIP_TRY(launch_resolve_records(ra, s));
     HIP_TRY(hipStreamSynchronize(s));  // (d_cols / rc live until here)
   }
-  const uint64_t* d_src = resolved ? d_wire.p : d_rec.p;
+  const uint64_t* d_src = resolved ? d_wire.p : d_records;
 
   // ---- 3. bucket by owner ---------------------------------------------------------------------
   std::vector<uint64_t> send_counts(N, 0), starts(N + 1, 0);
   WsBuf<uint64_t> d_send(x, 3), d_aux(x, 4);
   HIP_TRY(d_send.alloc(std::max<uint64_t>(n, 1) * rw * 8));
+  const uint64_t* d_out = d_send.p;  // what is sent
   HIP_TRY(d_aux.alloc((3 * kMaxExchangeRanks + 4) * 8));
   uint64_t* d_counts = d_aux.p;
   uint64_t* d_starts = d_aux.p + kMaxExchangeRanks;
@@ -589,8 +599,13 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     HIP_TRY(hipMemcpyAsync(d_starts, starts.data(), (N + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_owner_scatter(d_src, n, rw, uint32_t(N), d_starts, d_cursors, d_send, s));
   } else {
-    // every rank gets every record: "bucket" r = all of them
-    HIP_TRY(hipMemcpyAsync(d_send, d_src, n * rw * 8, hipMemcpyDeviceToDevice, s));
+    // every rank gets every record: "bucket" r = all of them (copied only when the string
+    // words are about to be rewritten in place, step 4)
+    if (resolved && !str_cols.empty()) {
+      HIP_TRY(hipMemcpyAsync(d_send, d_src, n * rw * 8, hipMemcpyDeviceToDevice, s));
+    } else {
+      d_out = d_src;
+    }
     for (int r = 0; r < N; ++r) send_counts[r] = n;
     starts[0] = 0;
     for (int r = 1; r <= N; ++r) starts[r] = n;  // (one segment)
@@ -679,13 +694,17 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     // GATHER_ALL: the same n records to everybody -- as an all-to-all whose send
     // segments coincide (the transports read `send_counts[r]` words at the running
     // offset, so the buffer is replicated per destination only logically)
-    WsBuf<uint64_t> d_rep(x, 8);
-    HIP_TRY(d_rep.alloc(std::max<uint64_t>(n * rw * N, 1) * 8));
-    for (int r = 0; r < N; ++r) {
-      HIP_TRY(hipMemcpyAsync(d_rep.p + uint64_t(r) * n * rw, d_send, n * rw * 8,
-                             hipMemcpyDeviceToDevice, s));
+    if (N == 1) {
+      rc = x->tr.all_to_all_words(x->tr.user, d_out, send_words.data(), d_recv, recv_words.data(), s);
+    } else {
+      WsBuf<uint64_t> d_rep(x, 8);
+      HIP_TRY(d_rep.alloc(std::max<uint64_t>(n * rw * N, 1) * 8));
+      for (int r = 0; r < N; ++r) {
+        HIP_TRY(hipMemcpyAsync(d_rep.p + uint64_t(r) * n * rw, d_out, n * rw * 8,
+                               hipMemcpyDeviceToDevice, s));
+      }
+      rc = x->tr.all_to_all_words(x->tr.user, d_rep, send_words.data(), d_recv, recv_words.data(), s);
     }
-    rc = x->tr.all_to_all_words(x->tr.user, d_rep, send_words.data(), d_recv, recv_words.data(), s);
     if (rc == EVQL_OK) HIP_TRY(hipStreamSynchronize(s));
   }
   if (rc != EVQL_OK) return Status::error(rc, "exchange: transfer of the records failed");
