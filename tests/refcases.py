@@ -75,6 +75,78 @@ class RefNestedGen(NestedGen, RefGen):
         return kw
 
 
+class RefStrGen(RefGen):
+    """string-PRODUCING expressions in the select list (expressions/string.cc,
+    conversion.cc:140-215, math.cc add#string): random trees over the string columns,
+    conversions of integer / float / bool expressions and of aggregates"""
+    str_cols = ("s", "ns")
+    str_lits = ("", "x", "G", "g1", " pad  ", "Key-", "7")
+
+    def strx(self, depth=0):
+        r = self.r
+        c = r.random()
+        if depth > 2 or c < 0.3:
+            return Col(r.choice(self.str_cols))
+        if c < 0.5:
+            # (a literal on one side only: the reference folds constant calls)
+            a, b = self.strx(depth + 1), Lit(r.choice(self.str_lits))
+            return Call("concat", a, b) if r.random() < 0.5 else Call("concat", b, a)
+        if c < 0.6:
+            return Call("concat", self.strx(depth + 1), self.strx(depth + 1))
+        if c < 0.75:
+            return Call(r.choice(["lcase", "ucase", "ltrim", "rtrim"]), self.strx(depth + 1))
+        if c < 0.9:
+            if r.random() < 0.6:
+                pos = Lit(r.choice([0, 1, 2, 3, 5, 9, 40]))
+            elif r.random() < 0.5:
+                pos = Call("mod", Col(r.choice(self.uint_cols)), Lit(r.choice([3, 6])))
+            else:
+                # wraps below zero: to_int64 makes it a position counted from the end
+                pos = Call("sub", Call("mod", Col(r.choice(self.uint_cols)), Lit(3)), Lit(r.choice([2, 4])))
+            return Call("substring", self.strx(depth + 1), pos)
+        return Call("to_string", self.stringable(depth + 1))
+
+    def stringable(self, depth=0):
+        r = self.r
+        c = r.random()
+        if c < 0.5:
+            return self.uint(depth + 1)
+        if c < 0.7:
+            return Col(r.choice(self.float_cols))
+        if c < 0.85:
+            return self.boolean(2)
+        return Col("t")
+
+    def plan_kwargs(self, row_ends):
+        r = self.r
+        c = r.random()
+        if c < 0.55:
+            keys = [Col(r.choice(["k", "k10", "nb"]))]
+        elif c < 0.85:
+            keys = [Col(r.choice(["s", "ns"]))]
+        elif c < 0.95:
+            keys = [Col("k10"), Col("ns")]
+        else:
+            keys = []
+        select = list(keys)
+        for _ in range(r.randint(1, 3)):
+            c = r.random()
+            if c < 0.7:
+                select.append(self.strx())
+            elif c < 0.85:
+                select.append(Call(r.choice(["startswith", "endswith"]), self.strx(1),
+                                   Lit(r.choice(self.str_lits))))
+            else:
+                select.append(Call("concat", Lit("n="), Call("to_string", self.aggregate())))
+        select.append(self.aggregate())
+        kw = dict(select=select, group_by=keys)
+        # (few groups: every string value of the result is compared)
+        kw["where"] = Call("logical_and", Call("lt", Col("k"), Lit(r.choice([8, 30, 120]))),
+                           self.boolean(1)) if r.random() < 0.6 else Call("lt", Col("k"), Lit(60))
+        kw["groups_hint"] = r.choice([0, 0, 1000])
+        return kw
+
+
 MIXED = dict(uint_cols=["k", "a", "b", "n", "p", "k10", "nb", "w"], float_cols=["v", "nv"],
              bool_cols=["f"], key_cols=["k", "k10", "f", "nb", "n", "s", "ns", "b"],
              first_cols=["a", "v", "s"], lits=[0, 1, 2, 7, 1000, 30000, 65535, 1 << 40])
@@ -133,6 +205,18 @@ def mixed_cases():
         g = RefGen(50_000 + seed, **MIXED)
         g.count_cols = MIXED_COUNT_COLS
         c = _case("mixed-%03d" % seed, "mixed", g.plan_kwargs([1]), T.MIXED_SCHEMA)
+        if c:
+            out.append(c)
+    return out
+
+
+@suite("strings")
+def strings_cases():
+    out = []
+    for seed in range(80):
+        g = RefStrGen(90_000 + seed, **MIXED)
+        g.count_cols = MIXED_COUNT_COLS
+        c = _case("strings-%03d" % seed, "mixed", g.plan_kwargs([1]), T.MIXED_SCHEMA)
         if c:
             out.append(c)
     return out

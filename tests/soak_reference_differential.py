@@ -3,7 +3,8 @@
 engine (oracle/_ref/csql_probe, built from /root/reference by oracle/ref_csql/build.sh),
 once with its CPU operators (MODE cpu) and once with the GPU operator plugged in (MODE gpu);
 rows must be identical.  Same generators as the committed fixtures (tests/refcases.py),
-other seeds; flat tables and the two nested ones (Dremel scans).
+other seeds; flat tables (incl. string-producing select expressions) and the two nested
+ones (Dremel scans).
 usage: tests/soak_reference_differential.py <first seed offset> <count> [families, e.g. items,testtbl
        | all] [partial]"""
 import json
@@ -18,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))  # (test infrastructure: lives u
 import refcases  # noqa: E402
 import sqlgen  # noqa: E402
 import tables as T  # noqa: E402
-from refcases import RefGen, RefNestedGen, MIXED, MIXED_COUNT_COLS, ITEMS, TESTTBL, _case  # noqa: E402
+from refcases import RefGen, RefNestedGen, RefStrGen, MIXED, MIXED_COUNT_COLS, ITEMS, TESTTBL, _case  # noqa: E402
 from eventql_amd import capi as K  # noqa: E402
 
 PROBE = os.path.join(ROOT, "oracle", "_ref", "csql_probe")
@@ -37,7 +38,7 @@ def dremel_scan_well_defined(programs):
 
 def cases(first, count):
     import nested_tables as N
-    out = {"mixed": [], "ranges": [], "items": [], "testtbl": []}
+    out = {"mixed": [], "ranges": [], "items": [], "testtbl": [], "strings": []}
     for seed in range(first, first + count):
         which = seed % 2
         table, schema, cols = (("items", N.ITEMS_SCHEMA, ITEMS) if which == 0 else
@@ -58,6 +59,11 @@ def cases(first, count):
         c = _case("mixed-s%d" % seed, "mixed", g.plan_kwargs([1]), T.MIXED_SCHEMA)
         if c:
             out["mixed"].append(c)
+        g = RefStrGen(180_000 + seed, **MIXED)
+        g.count_cols = MIXED_COUNT_COLS
+        c = _case("strings-s%d" % seed, "mixed", g.plan_kwargs([1]), T.MIXED_SCHEMA)
+        if c:
+            out["strings"].append(c)
         g = RefGen(160_000 + seed, **T.RANGES)
         c = _case("ranges-s%d" % seed, "ranges", g.plan_kwargs([1]), T.RANGES_SCHEMA)
         if c:
@@ -95,7 +101,7 @@ def main():
         for table, cs in cases(first, count).items():
             if want and table not in want:
                 continue
-            img, _, kind = refcases.table_image(table)
+            img, _, kind = refcases.table_image("mixed" if table == "strings" else table)
             path = os.path.join(tmp, table + ".cst")
             with open(path, "wb") as f:
                 f.write(img)

@@ -121,6 +121,8 @@ def _eval(e):
         return K.T_BOOL, (a and b) if n == "logical_and" else (a or b)
     if n == "neg":
         return K.T_BOOL, not bool(vals[0][1])
+    if len(vals) != 2:
+        raise FoldError("cannot fold %s" % n)
     (ta, a), (tb, b) = vals
     if ta != tb:
         raise FoldError("mixed literal types")

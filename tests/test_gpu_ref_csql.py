@@ -103,7 +103,7 @@ def test_hip_path_reproduces_the_reference(gpu_tables, suite, cid):
 def test_lowered_share(gpu_tables):
     """the flat suites must actually run on the device, not skip their way to green"""
     lowered = total = 0
-    for suite in ("survey", "mixed", "ranges"):
+    for suite in ("survey", "mixed", "ranges", "strings"):
         for fx in load(suite)["cases"]:
             if "programs" not in fx:
                 continue
