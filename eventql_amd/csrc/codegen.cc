@@ -118,7 +118,8 @@ struct Emitter {
         break;
     }
     const int fam = e->family, ts = e->type_slot;
-    if (ts == EVQL_TS_STRING && fam >= EVQL_FAM_CMP && fam <= EVQL_FAM_GTE) {
+    if (ts == EVQL_TS_STRING && ((fam >= EVQL_FAM_CMP && fam <= EVQL_FAM_GTE) ||
+                                 fam == EVQL_FAM_STARTSWITH || fam == EVQL_FAM_ENDSWITH)) {
       // operands are string columns / literals (planner.cc strings_lowerable)
       const std::string l = str_operand(e->args[0]), r = str_operand(e->args[1]);
       const std::string c = "evql_str_cmp(" + l + ", " + r + ")";
@@ -130,6 +131,8 @@ struct Emitter {
         case EVQL_FAM_LTE: rhs = "(" + c + " <= 0)"; break;
         case EVQL_FAM_GT: rhs = "(" + c + " > 0)"; break;
         case EVQL_FAM_GTE: rhs = "(" + c + " >= 0)"; break;
+        case EVQL_FAM_STARTSWITH: rhs = "evql_str_affix(" + l + ", " + r + ", false)"; break;
+        case EVQL_FAM_ENDSWITH: rhs = "evql_str_affix(" + l + ", " + r + ", true)"; break;
         default: rhs = "((i64) " + c + ")";
       }
       std::string t = fresh("t");

@@ -278,6 +278,16 @@ __device__ __forceinline__ bool evql_str_eq(const EvqlStr& a, const EvqlStr& b) 
   }
   return true;
 }
+// startswith / endswith (expressions/string.cc:52-74, StringUtil::beginsWith / endsWith:
+// std::string::compare over the affix -- bytewise, NULs included)
+__device__ __forceinline__ bool evql_str_affix(const EvqlStr& s, const EvqlStr& affix, bool at_end) {
+  if (s.len < affix.len) return false;
+  const u32 off = at_end ? s.len - affix.len : 0;
+  for (u32 i = 0; i < affix.len; ++i) {
+    if (evql_str_byte(s, off + i) != evql_str_byte(affix, i)) return false;
+  }
+  return true;
+}
 // strncmp over the common prefix (stops at a NUL both sides share), then length
 __device__ __forceinline__ int evql_str_cmp(const EvqlStr& a, const EvqlStr& b) {
   const u32 n = a.len < b.len ? a.len : b.len;

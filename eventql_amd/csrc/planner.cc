@@ -50,14 +50,15 @@ bool has_input(const ExprPtr& e) {
 bool is_bare_input(const ExprPtr& e) { return e && e->kind == Expr::INPUT; }
 
 bool is_string_compare(const ExprPtr& e) {
-  return e->kind == Expr::CALL && e->type_slot == EVQL_TS_STRING && e->family >= EVQL_FAM_CMP &&
-         e->family <= EVQL_FAM_GTE;
+  if (e->kind != Expr::CALL || e->type_slot != EVQL_TS_STRING) return false;
+  return (e->family >= EVQL_FAM_CMP && e->family <= EVQL_FAM_GTE) ||
+         e->family == EVQL_FAM_STARTSWITH || e->family == EVQL_FAM_ENDSWITH;
 }
 
 // Strings on the device: a bare column reference flows through untouched (as
 // its hash, for keys / first-row values), and string columns / literals may be
-// the operands of eq / neq / lt / lte / gt / gte / cmp (bytewise compare in the
-// kernel).  Anything else that produces or consumes a string (concat, IF over
+// the operands of eq / neq / lt / lte / gt / gte / cmp / startswith / endswith (bytewise
+// compare in the kernel).  Anything else that produces or consumes a string (concat, IF over
 // strings, to_string ...) is not lowered.
 bool strings_lowerable(const ExprPtr& e, bool root = true) {
   if (!e) return true;

@@ -219,6 +219,32 @@ def strings_cases():
         c = _case("strings-%03d" % seed, "mixed", g.plan_kwargs([1]), T.MIXED_SCHEMA)
         if c:
             out.append(c)
+    # startswith / endswith as predicates and keys: evaluated per row on the device
+    k10, a, s, ns = Col("k10"), Col("a"), Col("s"), Col("ns")
+    affix = [
+        dict(select=[k10, Agg("count", Lit(1)), Agg("sum", a)], group_by=[k10],
+             where=Call("startswith", s, Lit("g1"))),
+        dict(select=[k10, Agg("count", Lit(1))], group_by=[k10], where=Call("endswith", s, Lit("7"))),
+        dict(select=[Agg("count", Lit(1)), Agg("sum", a)], group_by=[],
+             where=Call("logical_and", Call("startswith", ns, Lit("s4")),
+                        Call("neg", Call("endswith", ns, Lit("9"))))),
+        dict(select=[Agg("count", Lit(1))], group_by=[], where=Call("startswith", s, Lit(""))),
+        dict(select=[Agg("count", Lit(1))], group_by=[], where=Call("endswith", ns, Lit(""))),
+        dict(select=[Agg("count", Lit(1))], group_by=[],
+             where=Call("startswith", s, Lit("g123456789012345678901234567890"))),
+        dict(select=[Call("startswith", s, Lit("g9")), Agg("count", Lit(1)), Agg("sum", a)],
+             group_by=[Call("startswith", s, Lit("g9"))]),
+        dict(select=[Call("endswith", ns, Lit("0")), k10, Agg("count", Lit(1))],
+             group_by=[Call("endswith", ns, Lit("0")), k10], where=Call("lt", Col("k"), Lit(300))),
+        dict(select=[s, Agg("count", Lit(1))], group_by=[s],
+             where=Call("logical_or", Call("endswith", s, Lit("99")), Call("startswith", s, s))),
+        dict(select=[k10, Agg("sum", If(Call("startswith", s, Lit("g2")), a, Lit(0)))], group_by=[k10],
+             where=Call("gte", a, Lit(0))),
+    ]
+    for i, kw in enumerate(affix):
+        c = _case("strings-affix-%02d" % i, "mixed", kw, T.MIXED_SCHEMA)
+        assert c is not None, i
+        out.append(c)
     return out
 
 
