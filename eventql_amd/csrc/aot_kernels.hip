@@ -205,8 +205,9 @@ __global__ void k_gather_rows(const u8* image, const RtColumn* cols, u32 ncols,
     const u64 r = rows[i];
     for (u32 c = 0; c < ncols; ++c) {
       const RtColumn col = cols[c];
-      out_vals[(u64) c * n + i] = rt_column_value(image, col, r);
-      out_tags[(u64) c * n + i] = col.tags ? col.tags[r] : 0;
+      // (an unrecorded first row reads as NULL instead of an address far outside the table)
+      out_vals[(u64) c * n + i] = r == EVQL_EMPTY ? 0 : rt_column_value(image, col, r);
+      out_tags[(u64) c * n + i] = r == EVQL_EMPTY ? 1 : (col.tags ? col.tags[r] : 0);
     }
   }
 }
@@ -384,6 +385,11 @@ __global__ void __launch_bounds__(kBlock) k_resolve_records(ResolveArgs a) {
     u64 tags = 0;
     for (u32 c = 0; c < a.ncols; ++c) {
       const RtColumn col = a.cols[c];
+      if (row == EVQL_EMPTY) {  // (unrecorded: NULL, not an address far outside the table)
+        out[a.in_words + c] = 0;
+        tags |= 1ull << c;
+        continue;
+      }
       out[a.in_words + c] = rt_column_value(a.image, col, row);
       if (col.tags && (col.tags[row] & 1)) tags |= 1ull << c;
     }

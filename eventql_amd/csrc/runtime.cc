@@ -2766,7 +2766,14 @@ static Status fetch_results(evql_query* q) {
     const uint32_t nc = uint32_t(kp.cols.size());
     std::vector<uint64_t> rows(n);
     const size_t rw = nwords + 1;
-    for (uint64_t i = 0; i < n; ++i) rows[i] = q->records[i * rw + 1 + kp.first_row_word()];
+    // (never hand an unrecorded first row to the gather: it would read far outside the table)
+    const uint64_t row_limit = q->nested ? q->nested_rows : t->layout.num_rows;
+    for (uint64_t i = 0; i < n; ++i) {
+      rows[i] = q->records[i * rw + 1 + kp.first_row_word()];
+      if (rows[i] >= row_limit) {
+        return Status::error(EVQL_ERUNTIME, "a group's first row was not recorded");
+      }
+    }
     std::vector<RtColumn> rc(nc);
     for (uint32_t c = 0; c < nc; ++c) {
       const ColAccess& ca = kp.cols[c];

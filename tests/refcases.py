@@ -245,6 +245,26 @@ def strings_cases():
         c = _case("strings-affix-%02d" % i, "mixed", kw, T.MIXED_SCHEMA)
         assert c is not None, i
         out.append(c)
+    # no GROUP BY, non-aggregate select expressions: the ONE group's values come from the
+    # first row that passes WHERE (groupby.cc:161-172)
+    v, p, k = Col("v"), Col("p"), Col("k")
+    glob = [
+        dict(select=[ns, Call("ucase", s), p, Agg("count", Lit(1))], group_by=[],
+             where=Call("logical_and", Call("lt", k, Lit(60)), Call("gt", a, Lit(1000)))),
+        dict(select=[Call("concat", ns, Lit("x")), Agg("sum", a)], group_by=[],
+             where=Call("gt", a, Lit(65000))),
+        dict(select=[s, Agg("count", Lit(1))], group_by=[], where=Call("gt", v, Lit(9.0e9))),
+        # (`p + count(1)` -- an input beside the aggregate -- trips an assertion in the
+        # reference, vm.cc:139: not pinnable)
+        dict(select=[p, v, Call("add", Agg("count", Lit(1)), Lit(7))], group_by=[],
+             where=Call("eq", Call("mod", a, Lit(9973)), Lit(17))),
+        dict(select=[ns, Agg("count_distinct", k)], group_by=[],
+             where=Call("logical_and", Call("lt", k, Lit(30)), Call("lte", Lit(1.5), v))),
+    ]
+    for i, kw in enumerate(glob):
+        c = _case("strings-global-%02d" % i, "mixed", kw, T.MIXED_SCHEMA)
+        assert c is not None, i
+        out.append(c)
     return out
 
 

@@ -322,6 +322,33 @@ def test_multi_column_keys_and_first_row(mixed):
     check(t, img, select=[col("a") % 10, count(1), sum_(col("b"))], group_by=[col("a") % 10])
 
 
+def test_global_group_reads_its_first_passing_row(mixed):
+    """no GROUP BY, non-aggregate select expressions: the one group's values are those of
+    the first row that passes WHERE (groupby.cc:161-172) -- found by the round-3 soak: the
+    ungrouped kernel path never recorded that row and the gather read outside the table"""
+    t, img, _ = mixed
+    a, k, v = col("a"), col("k"), col("v")
+    for where in (None, (k < 60) & (a > 1000), a > 65000, (a % 9973).eq(17), v > 9.0e9):
+        kw = dict(where=where) if where is not None else {}
+        check(t, img, key_cols=0, select=[col("ns"), col("s"), col("p"), col("nv"), count(1), sum_(a)], **kw)
+        check(t, img, key_cols=0, select=[Call("concat", col("ns"), "x"), Call("to_string", col("nb")),
+                                          count(1)], **kw)
+    # a row range and a row filter move the first row
+    check(t, img, key_cols=0, select=[col("s"), col("a"), count(1)], where=a > 60000, row_end=250000)
+    flt = np.zeros(300_000, dtype=bool)
+    flt[123_457::3] = True
+    check(t, img, key_cols=0, select=[col("s"), col("n"), count(1)], where=a > 50000, row_filter=flt)
+    # the PartialGroupBy row of the global group carries the encoded first-row values
+    plan = Plan(T.MIXED_SCHEMA, mode=K.MODE_PARTIAL, select=[col("ns"), col("p"), count(1), sum_(a)],
+                where=(k < 60) & (a > 1000))
+    exp = O.oracle_run(img, plan)
+    q = t.query(plan)
+    got = q.run()
+    assert got.nrows == exp.nrows == 1
+    assert dict(got.rows()) == {exp.keys[:20]: exp.columns[0][0]}
+    q.close()
+
+
 def test_expressions(mixed):
     t, img, _ = mixed
     a, b, v, k, p = col("a"), col("b"), col("v"), col("k"), col("p")
