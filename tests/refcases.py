@@ -427,6 +427,9 @@ def lsm_cases():
         ("two-keys", dict(select=[k, s, Agg("count", Lit(1))], group_by=[k, s])),
         ("high-card", dict(select=[Call("mod", rid, Lit(977)), Agg("count", Lit(1)), Agg("sum", a)],
                            group_by=[Call("mod", rid, Lit(977))])),
+        # no GROUP BY: the one group's values come from the first row the cursor lets through
+        ("global-first-row", dict(select=[rid, s, a, Agg("count", Lit(1))], group_by=[],
+                                  where=Call("gt", a, Lit(20000)))),
     ]
     out = []
     for pi, pname in enumerate(sorted(lsm_tables.PARTITIONS)):
@@ -472,6 +475,10 @@ def sibling_cases():
         ("two-key-columns", dict(select=[cq, sp, one, Agg("sum", cp)], group_by=[cq, sp])),
         ("bool-leaf", dict(select=[rc, one, Agg("sum", cq), Agg("count_distinct", pt)], group_by=[rc])),
         ("global", dict(select=[one, Agg("sum", cq), Agg("sum", pt), Agg("sum", rp)], group_by=[])),
+        # no GROUP BY, non-aggregates: the values of the first emitted row
+        ("global-first-row", dict(select=[cq, ci, sid, one, Agg("sum", pt)], group_by=[])),
+        ("global-first-row-one-group", dict(select=[rp, rc, sn, one], group_by=[],
+                                            where=Call("gt", rp, Lit(3)))),
         # a real predicate over columns of ONE depth (both groups at depth 1)
         ("where-depth-1", dict(select=[cq, one, Agg("sum", pt)], group_by=[cq],
                                where=Call("logical_or", Call("gt", cq, Lit(1)), Call("gt", pt, Lit(0))))),
