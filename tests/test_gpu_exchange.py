@@ -162,6 +162,22 @@ def test_first_row_values_travel_with_the_groups():
                 assert (s, a) == first0[k]
 
 
+def test_global_group_first_row_travels_too():
+    """no GROUP BY: the one group's non-aggregate values are those of rank 0's first
+    passing row; the aggregates cover every rank"""
+    parts = [partition(17, 30_000), partition(18, 30_000), partition(19, 20_000)]
+    kw = dict(select=[col("s"), col("a"), col("ns"), count(1), sum_(col("a"))], group_by=[],
+              where=col("a") > 60000)
+    for mode in (K.EXCHANGE_GATHER_ALL, K.EXCHANGE_BY_OWNER):
+        res = run_ranks(3, parts, kw, mode)
+        exp0 = O.oracle_run(image_of([parts[0]]), Plan(S, **kw)).rows()[0]
+        both = O.oracle_run(image_of(parts), Plan(S, **kw)).rows()[0]
+        rows = [row for rows, _, _ in res for row in rows]
+        assert len(rows) == (3 if mode == K.EXCHANGE_GATHER_ALL else 1)
+        for row in rows:
+            assert tuple(row[:3]) == tuple(exp0[:3]) and tuple(row[3:]) == tuple(both[3:])
+
+
 def test_custom_transport_callbacks():
     """a transport supplied through evql_transport_t (here: python callbacks that move
     the device buffers with torch, two ranks in two threads)"""

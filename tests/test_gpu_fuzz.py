@@ -219,6 +219,21 @@ def test_random_plan(mixed, seed):
     run_case(t, img, T.MIXED_SCHEMA, kw, partial_too=True)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_global_group_with_first_row_values(mixed, seed):
+    """no GROUP BY, non-aggregate select expressions beside the aggregates: the values of
+    the first row that passes WHERE / the row filter (groupby.cc:161-172)"""
+    t, img = mixed
+    g = Gen(7_000 + seed, **MIXED)
+    g.nrows = 300_000
+    kw = g.plan_kwargs([1, 4097, 131073, 250000])
+    r = random.Random(seed)
+    firsts = [Col(c) for c in r.sample(["a", "v", "s", "ns", "n", "nb", "p", "f", "k10"], r.randint(1, 3))]
+    kw["select"] = firsts + [e for e in kw["select"] if isinstance(e, Agg)] + [Agg("count", Lit(1))]
+    kw["group_by"] = []
+    run_case(t, img, T.MIXED_SCHEMA, kw, partial_too=True)
+
+
 # ---- nested (Dremel) scans ------------------------------------------------------------------
 def _nested_gens():
     import nested_tables as N
