@@ -3007,9 +3007,18 @@ static void save_state(const evql_query* q, const AggPlan& a, const uint64_t* st
       }
       out->insert(out->end(), p, p + 8);
       return;
-    default:
-      put_varuint(out, st[a.first_word + 1]);
-      out->insert(out->end(), p, p + 8);
+    default: {
+      // min / max / mean.  A group without a non-NULL value: the state word still holds the
+      // operation's identity (min: all ones) -- on the wire an untouched state is 0
+      const uint64_t cnt = st[a.first_word + 1];
+      put_varuint(out, cnt);
+      static const uint8_t zero[8] = {0};
+      if (cnt == 0) {
+        out->insert(out->end(), zero, zero + 8);
+      } else {
+        out->insert(out->end(), p, p + 8);
+      }
+    }
   }
 }
 

@@ -424,3 +424,16 @@ def test_first_rows_survive_a_bucketed_merge():
     assert len(rows) == both.nrows
     for u, s, a, c in rows:
         assert c == counts[u] and (s, a) == first[u]
+
+
+def test_partial_rows_after_a_bucketed_merge():
+    """EVQL_MODE_PARTIAL plans exchange their groups the same way: the rows emitted from the
+    dense merged records are the PartialGroupByExpression rows of the concatenated table"""
+    parts = [big_partition(500 + r, 330_000, 1_200_000) for r in range(3)]
+    pkw = dict(select=[col("s"), count(1), sum_(col("a"))], group_by=[col("s")],
+               groups_hint=500_000, mode=K.MODE_PARTIAL)
+    ep = O.oracle_run(image_of(parts), Plan(S, **pkw))
+    want = sorted((ep.keys[20 * i:20 * i + 20], ep.columns[0][i]) for i in range(ep.nrows))
+    res = run_ranks(3, parts, pkw, K.EXCHANGE_BY_OWNER)
+    assert all(st["merge_buckets"] > 0 for _, _, st in res)
+    assert sorted(r for rows, _, _ in res for r in rows) == want
