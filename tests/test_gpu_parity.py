@@ -1347,6 +1347,21 @@ def test_partitioned_path_with_a_dominant_key(ctx):
         t.close()
 
 
+def test_partitioned_path_with_a_handful_of_keys(mixed):
+    """a hint of 3e6 groups over rows that hold 3 .. 40 keys: every tuple lands in a few
+    coarse buckets, which overflow their slack -- whichever they are, the last range of
+    the buffer included.  The void launch must not read or write outside its buffers
+    (found by the round-3 fuzz soak, seed 4155: evql_part_refine followed the overflowed
+    cursor past the end of the tuple buffer) and the fallback gives the reference's rows"""
+    t, img, _ = mixed
+    a, k, nb, n = col("a"), col("k"), col("nb"), col("n")
+    for key in ((nb * n + 1099511627776) % 3, k % 5 + 1000003, a % 40, (a % 7) * 2305843009213693951,
+                k % 3 + 17, k % 2 + 123456789012):
+        check(t, img, select=[key, mean(col("p") * 1000), max_(nb / (col("p") + 1)), count(1)],
+              group_by=[key], groups_hint=3_000_000, row_end=131073)
+        check(t, img, select=[key, count(1), sum_(a)], group_by=[key], groups_hint=3_000_000)
+
+
 def test_hint_less_plan_over_keys_that_follow_the_row_order(ctx):
     """a time-ordered table: the key grows with the row number, so a prefix of the scan
     holds a handful of groups while the table has 90,000.  The probe samples row ranges
