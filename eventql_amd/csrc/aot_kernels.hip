@@ -502,6 +502,10 @@ __global__ void __launch_bounds__(kBlock) k_bucket_scatter(BucketScatterArgs a) 
   __shared__ u64 gbase[256];
   __shared__ u8 sbin[kBucketTileMax];
   const u32 tid = threadIdx.x;
+  // (a region of the previous pass outgrew its slack: records were dropped, what the regions
+  // hold beyond them is stale -- the caller falls back to the table merge, nothing of this
+  // attempt is read)
+  if (a.in_counts && (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) return;
   const u64 vtiles = (u64) a.in_regions * a.tiles_per_region;
   for (u64 vt = blockIdx.x; vt < vtiles; vt += gridDim.x) {
     const u32 reg = (u32) (vt / a.tiles_per_region);
@@ -586,6 +590,7 @@ __device__ __forceinline__ int bucket_find(u64* tab, const BucketMergeArgs& a, c
                                            bool claim, bool* fresh) {
   const u64 kind = rec[0];
   *fresh = false;
+  if (kind > 2) return -1;  // (not a record)
   if (kind != 0) {
     u64* key = tab + (u64) (a.lds_slots + (u32) kind - 1) * a.mw;
     if (claim) {
@@ -651,6 +656,7 @@ __global__ void __launch_bounds__(kBlock) k_bucket_merge(BucketMergeArgs a) {
   const u32 rw = a.mw + 1;
   const u32 nslots = a.lds_slots + 2;
   u32* order = (u32*) (tab + (u64) nslots * a.mw);
+  if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) return;  // (void attempt)
   for (u32 b = blockIdx.x; b < a.buckets; b += gridDim.x) {
     u64 cnt = a.counts[b];
     if (cnt > a.region_cap) cnt = a.region_cap;
