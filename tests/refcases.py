@@ -265,6 +265,21 @@ def strings_cases():
         c = _case("strings-global-%02d" % i, "mixed", kw, T.MIXED_SCHEMA)
         assert c is not None, i
         out.append(c)
+    # IF over strings (compiler.cc:174-209: only the branch taken is evaluated)
+    one = Agg("count", Lit(1))
+    ifs = [
+        dict(select=[k10, If(Call("gt", a, Lit(30000)), s, Lit("x")), one], group_by=[k10]),
+        dict(select=[k10, Call("concat", If(Call("gt", a, Lit(30000)), s, ns), Lit("!")), one],
+             group_by=[k10], where=Call("lt", k, Lit(200))),
+        dict(select=[k10, If(Call("gt", one, Lit(29990)), Lit("many"), Lit("few")), one], group_by=[k10]),
+        dict(select=[s, If(Call("startswith", s, Lit("g1")), Call("ucase", s), Call("to_string", a)), one],
+             group_by=[s], where=Call("lt", k, Lit(40))),
+        dict(select=[k10, Call("substring", If(Col("f"), ns, s), Lit(2)), one], group_by=[k10]),
+    ]
+    for i, kw in enumerate(ifs):
+        c = _case("strings-if-%02d" % i, "mixed", kw, T.MIXED_SCHEMA)
+        assert c is not None, i
+        out.append(c)
     return out
 
 
