@@ -104,7 +104,9 @@ class RefStrGen(RefGen):
                 # wraps below zero: to_int64 makes it a position counted from the end
                 pos = Call("sub", Call("mod", Col(r.choice(self.uint_cols)), Lit(3)), Lit(r.choice([2, 4])))
             return Call("substring", self.strx(depth + 1), pos)
-        return Call("to_string", self.stringable(depth + 1))
+        if c < 0.96:
+            return Call("to_string", self.stringable(depth + 1))
+        return If(self.boolean(2), self.strx(depth + 1), self.strx(depth + 1))
 
     def stringable(self, depth=0):
         r = self.r
