@@ -687,7 +687,8 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     recv_words[r] = recv_rec[r] * rw;
   }
   WsBuf<uint64_t> d_recv(x, 7);
-  HIP_TRY(d_recv.alloc(std::max<uint64_t>(total_rec, 1) * rw * 8));
+  HIP_TRY(d_recv.alloc(std::max<uint64_t>(N == 1 ? 1 : total_rec, 1) * rw * 8));
+  const uint64_t* d_in = d_recv.p;  // the received records, rank by rank
   if (by_owner) {
     rc = x->tr.all_to_all_words(x->tr.user, d_send, send_words.data(), d_recv, recv_words.data(), s);
   } else {
@@ -695,7 +696,8 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
     // segments coincide (the transports read `send_counts[r]` words at the running
     // offset, so the buffer is replicated per destination only logically)
     if (N == 1) {
-      rc = x->tr.all_to_all_words(x->tr.user, d_out, send_words.data(), d_recv, recv_words.data(), s);
+      // a single rank receives exactly what it sends: merged where it lies
+      d_in = d_out;
     } else {
       WsBuf<uint64_t> d_rep(x, 8);
       HIP_TRY(d_rep.alloc(std::max<uint64_t>(n * rw * N, 1) * 8));
@@ -787,7 +789,7 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
   uint64_t cap = 0;
   bool bucketed = false;
   if (!has_distinct) {
-    Status stb = bucketed_merge(q, x, ma, ia.identity, d_recv, recv_rec, hbase, total_rec, &bucketed);
+    Status stb = bucketed_merge(q, x, ma, ia.identity, d_in, recv_rec, hbase, total_rec, &bucketed);
     if (!stb.ok()) return stb;
   }
   if (bucketed) {
@@ -821,9 +823,9 @@ Status exchange(evql_query* q, evql_exchange* x, int mode) {
       if (recv_rec[r]) {
         if (resolved) {
           ma.heap_base = hbase[r];
-          HIP_TRY(launch_table_merge_resolved(ma, d_recv.p + roff * rw, recv_rec[r], s));
+          HIP_TRY(launch_table_merge_resolved(ma, d_in + roff * rw, recv_rec[r], s));
         } else {
-          HIP_TRY(launch_table_merge(ma.m, d_recv.p + roff * rw, recv_rec[r], s));
+          HIP_TRY(launch_table_merge(ma.m, d_in + roff * rw, recv_rec[r], s));
         }
       }
       roff += recv_rec[r];
