@@ -4,7 +4,7 @@
 #   on the MI355X box (through gpurun):  bash scripts/harvest_kcache.sh
 #   afterwards, in the container:        tar -xJf gpurun_out/kcache.tar.xz -C eventql_amd
 # The cache is keyed by the fingerprint of the generated source: stale entries are never
-# used, a missing one is compiled (hiprtc) and added.  Cold suite 581 s, warm 284 s (r03).
+# used, a missing one is compiled (hiprtc) and added.  Cold suite 644 s, warm 294 s (r03).
 set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
