@@ -3225,6 +3225,12 @@ Status query_next_batch(evql_query* q, size_t max_rows, evql_column_buf_t* cols,
             const uint64_t off = q->first_str_off[uint64_t(c) * q->ngroups + g];
             v.str.assign(reinterpret_cast<const char*>(q->first_str_heap.data()) + off,
                          size_t(raw >> 40));
+            // A cell of the Dremel scan is a boxed SValue (CSTableScan.cc:300-330): a string
+            // of 11 bytes is exactly the 16 bytes of the inline buffer, whose last byte --
+            // the value's tag -- also holds STAG_INLINE (svalue.cc:346-368).  X_INPUT copies
+            // the bytes as they lie, so the tag 0x80 reaches the group key's SHA1
+            // (PartialGroupBy keys) and the output vectors.  Found by the round-3 soak.
+            if (q->nested && v.str.size() == 11) v.tag = 0x80;
           }
         } else if (ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float) {
           double d = double(raw);
@@ -3341,6 +3347,7 @@ static Status final_row_values(evql_query* q, uint64_t g, std::vector<Value>* ou
           const uint64_t off = q->first_str_off[uint64_t(c) * q->ngroups + g];
           v.str.assign(reinterpret_cast<const char*>(q->first_str_heap.data()) + off,
                        size_t(raw >> 40));
+          if (q->nested && v.str.size() == 11) v.tag = 0x80;  // (boxed cell, see query_next_batch)
         }
       } else if (ca.stype == EVQL_T_FLOAT64 && ca.from_uint_to_float) {
         double d = double(raw);

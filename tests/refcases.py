@@ -479,6 +479,7 @@ def sibling_cases():
     st, sp, sn = _c("event.search_query.time"), _c("event.search_query.page"), _c("event.search_query.num_result_items")
     rp, rc = _c("event.search_query.result_items.position"), _c("event.search_query.result_items.clicked")
     tm, sid = _c("time"), _c("session_id")
+    qs = _c("event.search_query.query_string")
     one = Agg("count", Lit(1))
     named = [
         ("two-groups", dict(select=[cq, one, Agg("sum", pt)], group_by=[cq])),
@@ -493,6 +494,10 @@ def sibling_cases():
         ("bool-leaf", dict(select=[rc, one, Agg("sum", cq), Agg("count_distinct", pt)], group_by=[rc])),
         ("global", dict(select=[one, Agg("sum", cq), Agg("sum", pt), Agg("sum", rp)], group_by=[])),
         # no GROUP BY, non-aggregates: the values of the first emitted row
+        # strings of 11 bytes ("kinderstuhl", "sonnenblume"): boxed, they fill the SValue's
+        # 16-byte inline buffer, and the PartialGroupBy key hashes the STAG_INLINE bit with them
+        ("string-key-of-11-bytes", dict(select=[qs, one, Agg("sum", sn)], group_by=[qs])),
+        ("string-key-of-11-bytes-two-keys", dict(select=[qs, sp, one], group_by=[qs, sp])),
         ("global-first-row", dict(select=[cq, ci, sid, one, Agg("sum", pt)], group_by=[])),
         ("global-first-row-one-group", dict(select=[rp, rc, sn, one], group_by=[],
                                             where=Call("gt", rp, Lit(3)))),

@@ -86,7 +86,7 @@ def test_hip_path_reproduces_the_reference(gpu_tables, suite, cid):
         r2 = run_gpu(t, DumpedPlan(fx["programs"], scan_mode=c["scan_mode"]))
         assert r2 is not None
         check_result(fx["result"], r2)
-    if fx["partial"]["ok"] and fx["result"]["ok"] and c["scan_mode"] == K.SCAN_FLAT:
+    if fx["partial"]["ok"] and fx["result"]["ok"]:
         try:
             q = t.query(Plan(schema, mode=K.MODE_PARTIAL, scan_mode=c["scan_mode"], **c["kw"]))
         except E.EvqlError as e:
