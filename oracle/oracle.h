@@ -13,7 +13,7 @@
  *     test/sql_testdata/testtbl.cst
  *   - csql half: checked against the reference's own csql engine compiled in place
  *     (oracle/ref_csql/build.sh -> oracle/_ref/csql_probe): results, PartialGroupBy
- *     bytes and compiled bytecode of 585 queries incl. GROUP BYs over
+ *     bytes and compiled bytecode of 587 queries incl. GROUP BYs over
  *     eventql::PartitionCursor, committed as tests/golden/ref_csql_*.json; plus the
  *     reference's test fixtures (test/sql/00001,00002,00014; Runtime_test.cc)
  *   - unpinned (absent from this snapshot of the reference): sum(float64), min, max,
