@@ -3075,6 +3075,7 @@ Status query_set_order(evql_query* q, const evql_sort_spec_t* specs, uint32_t n,
       ok.word = uint32_t(1 + kp.state_word_base() + a.first_word);
       switch (a.fn) {
         case EVQL_AGG_COUNT:
+        case EVQL_AGG_COUNT_DISTINCT_UINT64:  // (one word: the number of distinct values)
         case EVQL_AGG_SUM_UINT64: ok.type = 0; break;
         case EVQL_AGG_SUM_INT64: ok.type = 1; break;
         case EVQL_AGG_SUM_FLOAT64:

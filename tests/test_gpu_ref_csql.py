@@ -229,6 +229,12 @@ def test_order_by_and_limit_are_fused_into_the_operator():
         "select k, sum(a) as sa from t where a >= 0 group by k order by k;",
         # a sort expression the device cannot read from a group record: CPU OrderBy on top
         "select k, sum(a) as sa from t where a >= 0 group by k order by sa % 7, k limit 9;",
+        # count_distinct as the first sort key (round-3 soak: its state was read like a
+        # min / max -- value + count word -- and the group whose NEXT state word was 0 sorted
+        # as 0)
+        "select k, count_distinct(b % 2) as d, sum(k) as sk from t where a > 60000 and b >= 0 "
+        "group by k order by d desc, k limit 5;",
+        "select k, count_distinct(a) as d from t where a > 60000 group by k order by d desc, k limit 8;",
     ]
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "t.cst")
