@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refcases  # noqa: E402
 
 PROBE = os.path.join(ROOT, "oracle", "_ref", "csql_probe")
-KEYS = ["k", "b", "p", "k10", "a"]          # non-nullable unsigned columns of the mixed table
+KEYS = ["k", "b", "p", "k10", "a", "s", "w"]  # non-nullable columns of the mixed table (s: STRING)
 AGGS = ["count(1)", "sum(a)", "sum(b)", "sum(k)", "sum(p)", "count_distinct(k10)", "sum(a * 3 + b)"]
 
 
@@ -30,7 +30,7 @@ def query(seed):
     for i in r.sample(range(len(aggs)), r.randint(0, min(2, len(aggs)))):
         order.append("x%d%s" % (i, r.choice(["", " desc", " asc"])))
     order.append(key + r.choice(["", " desc"]))
-    where = " and ".join("%s >= 0" % c for c in ("a", "b", "k", "p", "k10"))
+    where = " and ".join("%s >= 0" % c for c in ("a", "b", "k", "p", "k10", "w")) + " and (s = '' or s != '')"
     if r.random() < 0.5:
         where += " and a > %d" % r.choice([1000, 30000, 60000])
     sql = "select %s from t where %s group by %s order by %s" % (", ".join(sel), where, key, ", ".join(order))
