@@ -1905,20 +1905,22 @@ __global__ void __launch_bounds__(kBlock) k_mask_parent(const u8* levels, const 
 // owned by the thread holding its level-0 slot: it adds the `head` partial sums
 // (rows before a window's first level-0 slot) of the following threads from LDS
 // and stores the total.  Only the records that cross a 2048-row tile boundary
-// (<= 2 per tile) are added atomically -- measured on MI355X, mixing plain stores
-// and atomics at window granularity cost 5.5 ms per 2.1e8 rows against 1.1 ms for
-// stores only (out[] is zero-filled by the caller).  All arrays are padded by
-// >= 8192 slots (padded_rows): windows and the peek behind the tile are readable.
+// (<= 2 per tile) need more: the owner stores what its tile holds, every tile writes the
+// sum of the rows in front of its first record start into tile_head[], and
+// k_within_record_carry adds those heads to the record they belong to -- one thread per
+// such record, plain loads and stores.  (Round 2 added them atomically into a zero-filled
+// out[]: the fill was 0.8 GB per aggregate and step.)  Measured on MI355X, mixing plain
+// stores and atomics at window granularity had cost 5.5 ms per 2.1e8 rows against 1.1 ms
+// for stores only.  All arrays are padded by >= 8192 slots (padded_rows): windows and the
+// peek behind the tile are readable.
 __global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
   __shared__ u64 s_head[kBlock];
   __shared__ u8 s_hz[kBlock];
   const u32 tid = threadIdx.x;
   const u64 tile = blockIdx.x;
   const u64 s0 = tile * kDecodeTile + (u64) tid * 8;
-  const u64 tile_end = (tile + 1) * kDecodeTile;
   u64 packed = 0;        // level bytes of the window (no level stream: all 0)
   u64 idx0 = s0;         // records started before row s0
-  bool tile_closed = true;  // the tile's last record ends with the tile
   if (a.leaf_levels) {
     packed = *reinterpret_cast<const u64*>(a.leaf_levels + s0);
     u32 cnt = 0;
@@ -1928,7 +1930,6 @@ __global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
     }
     u32 total;
     idx0 = a.rec_offsets[tile] + block_excl_scan(cnt, &total);
-    tile_closed = tile_end >= a.nflat || a.leaf_levels[tile_end] == 0;
   }
   // has_zero: the window holds a level-0 slot; a window behind the last row ends
   // every chain with an empty head
@@ -1965,7 +1966,7 @@ __global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
         if (lvl == 0) {
           if (!started) {
             head = acc;
-          } else if (idx - 1 < a.nrec && acc) {
+          } else if (idx - 1 < a.nrec) {
             out[idx - 1] = acc;  // record inside the window
           }
           acc = 0;
@@ -1983,27 +1984,44 @@ __global__ void __launch_bounds__(kBlock) k_within_record(WithinRecordArgs a) {
       u64 sum = acc;
       u32 t = tid + 1;
       while (t < kBlock && !s_hz[t]) sum += s_head[t++];
-      const bool closed = t < kBlock || tile_closed;
       if (t < kBlock) sum += s_head[t];
-      if (idx - 1 < a.nrec && sum) {
-        if (closed) {
-          out[idx - 1] = sum;
-        } else {
-          atomicAdd(reinterpret_cast<unsigned long long*>(out + idx - 1), (unsigned long long) sum);
-        }
-      }
+      // (a record that runs on into the next tile: k_within_record_carry adds the rest)
+      if (idx - 1 < a.nrec) out[idx - 1] = sum;
     }
-    if (tid == 0 && idx0 > 0 && s0 < a.nflat && (packed & 0xff) != 0) {
-      // the tile starts inside record idx0 - 1 (it began in an earlier tile)
+    if (tid == 0 && a.tile_head[e]) {
+      // the rows in front of the tile's first record start belong to record idx0 - 1,
+      // which began in an earlier tile
       u64 sum = 0;
-      u32 t = 0;
-      while (t < kBlock && !s_hz[t]) sum += s_head[t++];
-      if (t < kBlock) sum += s_head[t];
-      if (idx0 - 1 < a.nrec && sum) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(out + idx0 - 1), (unsigned long long) sum);
+      if (idx0 > 0 && s0 < a.nflat && (packed & 0xff) != 0) {
+        u32 t = 0;
+        while (t < kBlock && !s_hz[t]) sum += s_head[t++];
+        if (t < kBlock) sum += s_head[t];
       }
+      a.tile_head[e][tile] = sum;
     }
     __syncthreads();
+  }
+}
+
+// One thread per tile that starts inside a record whose first row lies in the tile before
+// it: the heads of this tile and of the tiles behind it that hold no record start at all
+// are added to that record.  Every such record has exactly one thread.
+__global__ void __launch_bounds__(kBlock) k_within_record_carry(WithinRecordArgs a, u64 ntiles) {
+  const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 || t >= ntiles || t * kDecodeTile >= a.nflat) return;
+  if (a.leaf_levels[t * kDecodeTile] == 0) return;             // starts with a record
+  if (a.rec_offsets[t] == a.rec_offsets[t - 1]) return;        // the record began further back
+  const u64 rec = a.rec_offsets[t] - 1;
+  if (rec >= a.nrec) return;
+  u64 last = t;
+  while (last + 1 < ntiles && (last + 1) * kDecodeTile < a.nflat &&
+         a.rec_offsets[last + 1] == a.rec_offsets[last]) {
+    ++last;
+  }
+  for (u32 e = 0; e < a.n; ++e) {
+    u64 sum = 0;
+    for (u64 u = t; u <= last; ++u) sum += a.tile_head[e][u];
+    if (sum) ((u64*) a.out[e])[rec] += sum;
   }
 }
 
@@ -2343,6 +2361,9 @@ hipError_t launch_within_record(const WithinRecordArgs& a, hipStream_t s) {
   const u64 ntiles = (a.nflat + kDecodeTile - 1) / kDecodeTile;
   if (ntiles == 0) return hipSuccess;
   hipLaunchKernelGGL(k_within_record, dim3((unsigned) ntiles), dim3(kBlock), 0, s, a);
+  if (a.leaf_levels && ntiles > 1) {
+    hipLaunchKernelGGL(k_within_record_carry, dim3(grid_for(ntiles)), dim3(kBlock), 0, s, a, (u64) ntiles);
+  }
   return hipGetLastError();
 }
 

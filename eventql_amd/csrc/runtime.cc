@@ -1221,7 +1221,15 @@ static Status materialize_within_record(evql_query* q) {
     const evql_query::WithinAgg& w = q->wr_aggs[e];
     DevBuf<uint64_t> d_out;
     HIP_TRY(d_out.alloc(recp * 8));
-    HIP_TRY(hipMemsetAsync(d_out, 0, recp * 8, s));
+    // (every record is stored by the kernel: only the padding behind them is cleared)
+    if (recp > nrec) HIP_TRY(hipMemsetAsync(d_out.p + nrec, 0, (recp - nrec) * 8, s));
+    if (leaf.levels) {
+      const uint64_t ntiles = (nflat + kDecodeTile - 1) / kDecodeTile;
+      DevBuf<uint64_t> d_head;
+      HIP_TRY(d_head.alloc(std::max<uint64_t>(ntiles, 1) * 8));
+      a.tile_head[e] = d_head;
+      q->nested_owned.push_back(d_head.release());
+    }
     a.src[e] = w.col >= 0 ? flat[w.col] : nullptr;
     a.lit[e] = w.lit;
     a.level[e] = w.level;
